@@ -1,0 +1,178 @@
+/*
+ * rtx.h -- C ABI of the MI355X (gfx950) ray-trace hot path.
+ *
+ * This is the drop-in boundary for ONE path of EmilHogstedt/Raytracing-in-Windows-Console:
+ * RayTracingManager::Update -> RayTracing::RayTrace -> RayTrace_<MODE> kernels
+ * (primary-ray generation, sphere/plane closest hit, Blinn-Phong shading, ANSI record
+ * write) plus the Minimize pass and the UpdateObjects step that Update runs around it.
+ * Plain pointers and sizes only; every entry point returns an int status (0 = RTX_OK) and
+ * never exits the process.  Reference citations are file:line under ConsoleProject/.
+ *
+ * The reference has no FFI layer: its seams are in-process C++.  Each entry
+ * point below names the reference interface it replaces; include/rtx_compat.hpp rebuilds
+ * the reference's classes (RayTracingManager, RayTracing, Scene3D, ...) on top of this ABI,
+ * and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Threading: one caller per context, blocking unless a call says otherwise (the reference
+ * drives the path from its main thread only, Engine3D.cpp:81-107).
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Status codes. */
+enum rtx_status {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARGUMENT = 1,
+    RTX_ERR_INVALID_MODE = 2,    /* RayTracing.cu:863-865 asserts; this ABI reports */
+    RTX_ERR_HIP = 3,             /* a HIP runtime call failed: rtx_last_error() has the text (pch.h:45-53 exits instead) */
+    RTX_ERR_OUT_OF_MEMORY = 4,
+    RTX_ERR_NO_DEVICE = 5,       /* no gfx950 device visible: the product never falls back to a CPU path */
+    RTX_ERR_TOO_LARGE = 6        /* frame larger than the context was created for */
+};
+
+/* enum RenderingMode, RayTracingManager.h:21 (same values). */
+enum rtx_mode {
+    RTX_BIT_ASCII = 0,
+    RTX_BIT_PIXEL = 1,
+    RTX_RGB_ASCII = 2,
+    RTX_RGB_PIXEL = 3,
+    RTX_RGB_NORMALS = 4,
+    RTX_SDL = 5
+};
+
+/* Bytes per pixel record: SIZE_8BIT / SIZE_RGB, RayTracing.h:120-124. */
+#define RTX_SIZE_8BIT 12
+#define RTX_SIZE_RGB 20
+
+/* struct RayTracingCPUToGPUData, RayTracingManager.h:9-19: the logical payload without the
+ * six vptrs the reference's Matrix/Vector classes carry.  inv_v is row-major (row1..row4). */
+typedef struct rtx_params {
+    float inv_v[16];
+    float cam_pos[3];
+    float element1;  /* projection matrix [0][0], Engine3D.cpp:94 */
+    float element2;  /* projection matrix [1][1], Engine3D.cpp:95 */
+    float cam_far;   /* Engine3D.cpp:96 */
+    uint64_t x;      /* console width  W, Engine3D.cpp:92 */
+    uint64_t y;      /* console height H, Engine3D.cpp:93 */
+} rtx_params;
+
+/* Which kernel family renders (RTX_OPT_KERNEL). */
+enum rtx_kernel {
+    RTX_KERNEL_AUTO = 0,   /* binned when it pays, brute otherwise */
+    RTX_KERNEL_BRUTE = 1,  /* every pixel tests every object, scene tiles staged in LDS */
+    RTX_KERNEL_BINNED = 2  /* per-workgroup conservative frustum culling, then the same exact tests */
+};
+
+enum rtx_option {
+    RTX_OPT_KERNEL = 1,       /* enum rtx_kernel */
+    RTX_OPT_TILE_LOG2_W = 2   /* log2 of the workgroup tile width in pixels (2..6); 0 = choose from the camera */
+};
+
+/* Flags of rtx_render_rows. */
+enum rtx_render_flags {
+    RTX_RENDER_DEFAULT = 0,
+    /* 8-bit modes use only the first 12*W*H bytes of the 20*W*H frame (RayTracing.cu:238);
+     * with this flag the call also zero-fills bytes [12*W*H, 20*W*H) of a full-frame buffer,
+     * as the reference's per-frame cudaMemset leaves them (RayTracingManager.cu:86,161-165). */
+    RTX_RENDER_ZERO_TAIL = 1
+};
+
+/* ---- context: RayTracingManager::RayTracingManager / ~RayTracingManager (RayTracingManager.cu:53-74).
+ * Owns the device params block, the 20*max_w*max_h device result buffer (PrintMachine::GetMaxSize(),
+ * PrintMachine.cpp:140) and the scene store.  `device` is the HIP device ordinal. */
+int rtx_create(int device, size_t max_w, size_t max_h, rtx_ctx** out);
+void rtx_destroy(rtx_ctx* ctx);
+
+/* Text of the last error on this context (or of the last failed rtx_create when ctx is NULL). */
+const char* rtx_last_error(const rtx_ctx* ctx);
+const char* rtx_version(void);
+int rtx_set_option(rtx_ctx* ctx, int option, int64_t value);
+int rtx_get_option(const rtx_ctx* ctx, int option, int64_t* value);
+
+/* ---- scene: Scene3D::CreateSphere / CreatePlane / GetObjects (Scene3D.h:15-25, Scene3D.cpp:36-105).
+ * Append-only; creation order is the closest-hit tie-break order (RayTracing.cu:100-136).
+ * No 5 MB arena cap (Scene3D.h:6).  The add calls return the new object's index (>= 0) or -status. */
+int rtx_scene_clear(rtx_ctx* ctx);
+int rtx_scene_add_sphere(rtx_ctx* ctx, const float pos[3], float radius, const float rgb[3]);
+int rtx_scene_add_plane(rtx_ctx* ctx, const float pos[3], const float normal[3], const float rgb[3],
+                        float width, float height);
+/* Bulk append: n records of 7 floats (cx cy cz r R G B). */
+int rtx_scene_add_spheres(rtx_ctx* ctx, size_t n, const float* xyzr_rgb);
+unsigned rtx_scene_count(const rtx_ctx* ctx);
+/* Sphere::mover / Sphere::speed (Sphere.cu:9-12): the reference draws speed from rand(); here the caller sets it. */
+int rtx_scene_set_sphere_motion(rtx_ctx* ctx, unsigned index, int mover, float speed);
+/* Reads object `index` back from the device store: type (1 plane, 2 sphere, Object3D.h:14) and
+ * 11 floats (sphere: cx cy cz r R G B mover speed 0 0; plane: px py pz nx ny nz R G B w h). */
+int rtx_scene_get_object(rtx_ctx* ctx, unsigned index, int* type, float out[11]);
+
+/* ---- render: RayTracing::RayTrace (RayTracing.h:31-38, RayTracing.cu:797-867) together with the
+ * zero-fill that precedes it in RayTracingManager::Update (RayTracingManager.cu:86).
+ *
+ * rtx_render: whole frame into the context's own device buffer, which afterwards holds exactly
+ * the bytes the reference's buffer holds after memset + kernel (20*W*H of them).  Asynchronous
+ * on the context's stream, like the reference's launch; rtx_synchronize waits
+ * (RayTracingManager.cu:137). */
+int rtx_render(rtx_ctx* ctx, const rtx_params* params, int mode);
+
+/* Row-slab form for multi-GPU frames: traces rows [row0, row0+rows) with the GLOBAL row index in
+ * ray generation (RayTracing.cu:12,16) and writes each row r at d_out + (r - out_row_base)*W*S.
+ * d_out is device memory of the caller (NULL = the context's buffer, out_row_base then 0);
+ * `stream` is a hipStream_t (NULL = the context's stream). */
+int rtx_render_rows(rtx_ctx* ctx, const rtx_params* params, int mode, size_t row0, size_t rows,
+                    void* d_out, size_t out_row_base, void* stream, unsigned flags);
+
+int rtx_synchronize(rtx_ctx* ctx);
+
+/* The context's device result buffer (m_deviceResultArray, RayTracingManager.h:45) and its size. */
+void* rtx_frame_device_ptr(rtx_ctx* ctx);
+size_t rtx_frame_capacity(const rtx_ctx* ctx);
+/* Blocking device-to-host copy of the first `bytes` of that buffer (RayTracingManager.cu:143). */
+int rtx_read_frame(rtx_ctx* ctx, void* host_out, size_t bytes);
+
+/* ---- Minimize: RayTracingManager::MinimizeResults / Minimize8bit / MinimizeRGB
+ * (RayTracingManager.cu:167-319), on the GPU.  d_in is a 20*W*H frame in device memory (NULL =
+ * the context's buffer), d_out device memory with room for S*W*H bytes (NULL = the context's
+ * own minimise buffer).  *out_bytes receives the minimised length.  Blocking. */
+int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, void* d_out, size_t* out_bytes);
+void* rtx_minimized_device_ptr(rtx_ctx* ctx);
+
+/* ---- UpdateObjects: the physics kernel Update launches before tracing (RayTracingManager.cu:10-44,
+ * 89-107; Sphere.cu:15-23), with a launch shape that stays valid past 1024 objects. */
+int rtx_update_objects(rtx_ctx* ctx, double dt);
+
+/* ---- RayTracingManager::Update (RayTracingManager.cu:76-154) in one call: params upload, zero
+ * semantics, UpdateObjects(dt) when run_physics != 0, trace, GPU minimise, and the copy of the
+ * minimised stream to host_out (room for 20*W*H bytes).  On return *out_bytes is what the
+ * reference hands to PrintMachine::SetDataInBackBuffer (RayTracingManager.cu:150). */
+int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics,
+               void* host_out, size_t* out_bytes);
+
+/* ---- measurement helpers (bench.py): HIP events on the context's stream. */
+int rtx_timer_start(rtx_ctx* ctx);
+int rtx_timer_stop(rtx_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns start->stop */
+/* Name of the kernel the last rtx_render/rtx_render_rows launched (for matching rocprofv3 rows). */
+const char* rtx_last_kernel_name(const rtx_ctx* ctx);
+
+/* ---- host-side input builders (no GPU work; pure fp32 host math).
+ * rtx_camera_params: what Engine3D::Render fills (Engine3D.cpp:90-97) from Camera3D::Init/Update/
+ * GetInverseVMatrix (Camera3D.cpp:8-48, 51-98, 207-376) for a camera at pos with rotation
+ * (pitch, yaw, roll); NULL pos/rot = the reference's start pose (Camera3D.h:59-62). */
+int rtx_camera_params(size_t w, size_t h, const float pos[3], const float rot[3], rtx_params* out);
+/* SURVEY.md Appendix D synthetic scenes (the BASELINE.json configs): fills n_spheres*7 floats
+ * (cx cy cz r R G B) and n_planes*11 floats (px py pz nx ny nz R G B w h), n_planes <= 6. */
+int rtx_synth_scene(uint32_t seed, size_t n_spheres, size_t n_planes, float element1, float element2,
+                    float* spheres_out, float* planes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

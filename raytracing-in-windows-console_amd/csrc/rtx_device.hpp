@@ -1,0 +1,251 @@
+// rtx_device.hpp -- per-pixel arithmetic of the ray-trace hot path for gfx950 device code.
+//
+// Every function follows the reference's fp32 operation order exactly (SURVEY.md Appendix A;
+// citations are file:line under ConsoleProject/) so that results are bit-identical to an IEEE
+// evaluation of the reference: no FMA contraction (-ffp-contract=off), correctly rounded
+// sqrt and division (hipcc's default), no reassociation, denormals kept.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx {
+
+struct V3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+// MyMath.h:60-63, 74-77, 88-92
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 mulf(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+// MyMath.cu:5-8: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// MyMath.h:139-145: one reciprocal, three multiplies, no zero check
+__device__ __forceinline__ V3 normalize_gpu(V3 a)
+{
+    const float length = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return v3(a.x * length, a.y * length, a.z * length);
+}
+// MyMath.cu:29-34
+__device__ __forceinline__ float clampf(float v, float lo, float hi)
+{
+    const float r = v < lo ? lo : v;
+    return r > hi ? hi : r;
+}
+// MyMath.cu:59-62
+__device__ __forceinline__ float minf(float a, float b) { return a < b ? a : b; }
+
+// pow(x, 32.0f) of RayTracing.cu:73, pinned: five squarings in double, rounded once to float.
+// libm powf is not reproducible across libms; this routine is IEEE-exact on
+// CPU and GPU alike and is what the oracle evaluates by default.
+__device__ __forceinline__ float pow32(float x)
+{
+    double d = (double)x;
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    d = d * d;
+    return (float)d;
+}
+
+// (uint8_t)f as the CUDA hardware conversion does it: truncate; negatives and NaN give 0.
+__device__ __forceinline__ uint32_t u8_sat(float f)
+{
+    if (!(f > 0.0f)) {
+        return 0u;
+    }
+    if (f >= 4294967296.0f) {
+        return 255u;
+    }
+    return ((uint32_t)f) & 255u;
+}
+
+struct Ray {
+    V3 o, d;
+    float a, fourA, divTwoA;
+};
+
+struct Camera {
+    float m[12]; // first three rows of inverseVMatrix, row-major
+    float ox, oy, oz;
+    float e1, e2, far;
+    float fW, fH; // (float)W, (float)H
+};
+
+// CalculateInitialDirection, RayTracing.cu:9-24, and the per-ray constants of RayTracing.cu:91-93.
+__device__ __forceinline__ Ray make_ray(const Camera& c, uint32_t row, uint32_t col)
+{
+    const float convertedY = (c.fH - (float)(row * 2u)) / c.fH;
+    const float convertedX = ((float)(2u * col) - c.fW) / c.fW;
+    const float vx = convertedX * c.e1;
+    const float vy = convertedY * c.e2;
+    const float vz = 1.0f;
+    const float vw = 0.0f;
+    // Matrix::Mult, MyMath.h:310-319
+    V3 w;
+    w.x = c.m[0] * vx + c.m[1] * vy + c.m[2] * vz + c.m[3] * vw;
+    w.y = c.m[4] * vx + c.m[5] * vy + c.m[6] * vz + c.m[7] * vw;
+    w.z = c.m[8] * vx + c.m[9] * vy + c.m[10] * vz + c.m[11] * vw;
+    Ray r;
+    r.o = v3(c.ox, c.oy, c.oz);
+    r.d = normalize_gpu(w);
+    r.a = dot(r.d, r.d);
+    r.fourA = 4.0f * r.a;
+    r.divTwoA = 1.0f / (2.0f * r.a);
+    return r;
+}
+
+// Sphere::Trace, Sphere.cu:30-68, split in two.
+//
+// sphere_reject: the miss test on the hoisted terms otc = o - c and cc = Dot(otc,otc) - r*r
+// (ray-independent for primary rays, which all share the origin).  The reference evaluates
+// disc = b*b - fourA*cc with b = 2*s, fourA = 4*a.  Scaling by powers of two is exact, so
+// disc == 4 * (s*s - a*cc) bit for bit (barring subnormal s*s or a*cc, which needs
+// |o-c| or r below 1e-18); the sign test therefore runs on s*s - a*cc, one multiply fewer.
+__device__ __forceinline__ bool sphere_reject(const Ray& r, float ox, float oy, float oz, float cc, float& s)
+{
+    s = r.d.x * ox + r.d.y * oy + r.d.z * oz;
+    const float q = s * s - r.a * cc;
+    return q < 0.0f;
+}
+
+// sphere_hit: the literal reference arithmetic from the discriminant on; true with t set on a hit.
+__device__ __forceinline__ bool sphere_hit(const Ray& r, float s, float cc, float& t)
+{
+    const float b = 2.0f * s;
+    const float discriminant = b * b - r.fourA * cc;
+    if (discriminant < 0.0f) {
+        return false;
+    }
+    const float sqrtDiscriminant = sqrtf(discriminant);
+    const float minusB = -b;
+    const float t1 = (minusB + sqrtDiscriminant) * r.divTwoA;
+    const float t2 = (minusB - sqrtDiscriminant) * r.divTwoA;
+    if (t1 < 0.0f || t2 < 0.0f) {
+        return false;
+    }
+    t = minf(t1, t2);
+    return true;
+}
+
+// Plane::Trace, Plane.cu:38-72.
+__device__ __forceinline__ bool plane_hit(const Ray& r, V3 p, V3 n, float width, float height, float& t)
+{
+    const float dn = dot(r.d, n);
+    // FloatEquals(dn, 0.0f), MyMath.cu:43-47
+    if (dn > 0.0f || fabsf(dn - 0.0f) < 1.1920928955078125e-7f) {
+        return false;
+    }
+    const float t1 = dot(sub(p, r.o), n) / dn;
+    if (t1 <= 0.0f) {
+        return false;
+    }
+    const V3 hp = add(r.o, mulf(r.d, t1));
+    const float hw = width * 0.5f;
+    const float hh = height * 0.5f;
+    if ((hp.x <= p.x - hw || hp.x >= p.x + hw) || (hp.z <= p.z - hh || hp.z >= p.z + hh)) {
+        return false;
+    }
+    t = t1;
+    return true;
+}
+
+// BlinnPhongShading with the call-site constants, RayTracing.cu:41-79 and :143-157.
+// colour in: object colour (0..255 floats); out: shaded colour clamped to <= 255.
+__device__ __forceinline__ V3 shade(const Ray& r, float distance, V3 normal, V3 objColour)
+{
+    const V3 od = v3(objColour.x / 255.0f, objColour.y / 255.0f, objColour.z / 255.0f);
+    const V3 point = add(r.o, mulf(r.d, distance));
+    const V3 viewDir = normalize_gpu(mulf(r.d, -1.0f));
+
+    V3 lightDir = sub(v3(1.0f, 50.0f, 0.0f), point);
+    float dist = sqrtf(lightDir.x * lightDir.x + lightDir.y * lightDir.y + lightDir.z * lightDir.z);
+    dist = dist * dist;
+    const float divDistance = 1.0f / dist;
+    lightDir = normalize_gpu(lightDir);
+
+    const V3 nn = normalize_gpu(normal);
+    const V3 nv = normalize_gpu(viewDir);
+
+    const float diffuseIntensity = clampf(dot(nn, lightDir), 0.0f, 1.0f);
+    // lightDiffuseColour (1,1,1) * intensity * 2000 * divDistance, per component
+    const float diffuse = ((1.0f * diffuseIntensity) * 2000.0f) * divDistance;
+
+    const V3 h = normalize_gpu(add(lightDir, nv));
+    const float specularIntensity = pow32(clampf(dot(nn, h), 0.0f, 1.0f));
+    const float specular = ((1.0f * specularIntensity) * 3000.0f) * divDistance;
+
+    // ComponentMul(ambient, od) + ComponentMul(diffuse, od) + ComponentMul(specular, (1,1,1))
+    V3 res;
+    res.x = 0.2f * od.x + diffuse * od.x + specular * 1.0f;
+    res.y = 0.2f * od.y + diffuse * od.y + specular * 1.0f;
+    res.z = 0.2f * od.z + diffuse * od.z + specular * 1.0f;
+    res = mulf(res, 255.0f);
+    return v3(minf(255.0f, res.x), minf(255.0f, res.y), minf(255.0f, res.z));
+}
+
+// GetASCIICharacter's index, RayTracing.cu:26-39.  The reference clamps to 68, one past its
+// 68-entry table; the build resolves that to the last glyph.
+__device__ __forceinline__ int ramp_index(float shadingValue)
+{
+    int i = (int)ceilf(shadingValue * 67.0f);
+    i = i < 1 ? 1 : i;
+    return i > 67 ? 67 : i;
+}
+
+// xterm-256 mapping of ANSIRGB.h:114-189, written from the algorithm: palette entries are
+// computed, the grey lookup (256 bytes, generated on the host by rule) is read from `grey`.
+__device__ __forceinline__ uint32_t ansi_distance(uint32_t r1, uint32_t g1, uint32_t b1, uint32_t r2, uint32_t g2, uint32_t b2)
+{
+    const int32_t r_sum = (int32_t)(r1 + r2);
+    const int32_t r = (int32_t)r1 - (int32_t)r2;
+    const int32_t g = (int32_t)g1 - (int32_t)g2;
+    const int32_t b = (int32_t)b1 - (int32_t)b2;
+    return (uint32_t)((1024 + r_sum) * r * r + 2048 * g * g + (1534 - r_sum) * b * b);
+}
+
+__device__ __forceinline__ uint32_t cube_level(uint32_t v, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4)
+{
+    return (uint32_t)(v >= t0) + (uint32_t)(v >= t1) + (uint32_t)(v >= t2) + (uint32_t)(v >= t3) + (uint32_t)(v >= t4);
+}
+
+__device__ __forceinline__ uint32_t cube_value(uint32_t level) { return level == 0u ? 0u : 55u + 40u * level; }
+
+__device__ __forceinline__ uint32_t palette_grey_value(uint32_t index)
+{
+    // only indices the grey lookup produces: 16, 59, 102, 145, 188, 231 (cube diagonal) and 232..255
+    return index >= 232u ? 8u + 10u * (index - 232u) : cube_value((index - 16u) / 43u);
+}
+
+__device__ __forceinline__ uint32_t ansi256_from_rgb(uint32_t r, uint32_t g, uint32_t b, const uint8_t* __restrict__ grey)
+{
+    if (r == g && g == b) {
+        return grey[b];
+    }
+    const uint32_t lum = (3567664u * r + 11998547u * g + 1211005u * b + (1u << 23)) >> 24;
+    const uint32_t grey_index = grey[lum & 255u];
+    const uint32_t gv = palette_grey_value(grey_index);
+    const uint32_t grey_distance = ansi_distance(r, g, b, gv, gv, gv);
+    const uint32_t ir = cube_level(r, 38u, 115u, 155u, 196u, 235u);
+    const uint32_t ig = cube_level(g, 36u, 116u, 154u, 195u, 235u);
+    const uint32_t ib = cube_level(b, 35u, 115u, 155u, 195u, 235u);
+    const uint32_t cube_distance = ansi_distance(r, g, b, cube_value(ir), cube_value(ig), cube_value(ib));
+    return cube_distance < grey_distance ? 16u + 36u * ir + 6u * ig + ib : grey_index;
+}
+
+// Three decimal digits with NUL for absent leading digits (RayTracing.cu:212-229 and its
+// copies; equal to plain decimal for 0..255).  Returns d0 | d1 << 8 | d2 << 16.
+__device__ __forceinline__ uint32_t digits3(uint32_t v)
+{
+    const uint32_t h = v / 100u;
+    const uint32_t t = (v / 10u) % 10u;
+    const uint32_t u = v % 10u;
+    const uint32_t d0 = v >= 100u ? 48u + h : 0u;
+    const uint32_t d1 = v >= 10u ? 48u + t : 0u;
+    return d0 | (d1 << 8) | ((48u + u) << 16);
+}
+
+} // namespace rtx

@@ -1,0 +1,45 @@
+// rtx_kernels.h -- launch interface between the host API (rtx_api.cpp) and the gfx950 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+// Kernel-side mode numbers = enum RenderingMode (RayTracingManager.h:21).
+enum {
+    RTX_K_BIT_ASCII = 0,
+    RTX_K_BIT_PIXEL = 1,
+    RTX_K_RGB_ASCII = 2,
+    RTX_K_RGB_PIXEL = 3,
+    RTX_K_RGB_NORMALS = 4,
+    RTX_K_SDL = 5
+};
+
+// Kernel arguments, passed by value (they land in SGPRs through scalar loads).
+struct KArgs {
+    float m[12];          // first three rows of inverseVMatrix
+    float ox, oy, oz;     // camPos
+    float e1, e2, far;    // element1, element2, camFarDist
+    float fW, fH;         // (float)W, (float)H
+    uint32_t W, H;
+    uint32_t row0, row_end;   // rows traced by this launch (global row indices)
+    uint32_t out_row_base;    // the row stored at out[0]
+    uint32_t ns, np;          // spheres, planes
+    uint32_t tile_log2w;      // workgroup tile is 2^lw x 2^(8-lw) pixels
+    // Scene, SoA in HBM (creation order within each kind; .w of the colour arrays carries the
+    // creation index across kinds as uint bits):
+    const float4* sph_geom;   // cx cy cz r
+    const float4* sph_color;  // R G B gidx
+    const float4* pl_a;       // px py pz width
+    const float4* pl_b;       // nx ny nz height
+    const float4* pl_c;       // R G B gidx
+    const uint8_t* grey;      // 256-byte grey lookup of the xterm-256 mapper
+    uint8_t* out;             // records of row out_row_base start here
+};
+
+extern "C" {
+// Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
+// the hipGetLastError() value in *hip_error.
+const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
+int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
+}

@@ -1,0 +1,302 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed goldens.
+
+Bar: the ANSI character buffer is byte-exact (character indices, colour digits, layout).  The
+hit distances / colours behind it are fp32 and required to agree within 1e-5 relative
+(BASELINE.json north_star); since both sides evaluate the same IEEE operations in the same order
+the bytes agree exactly, which implies the tolerance.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+TOL_REL = 1e-5  # north_star tolerance on distances/colours; byte equality below is the stricter check
+
+
+@pytest.fixture(scope="module")
+def R():
+    return U.pkg()
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    c = R.Context(3840, 2160)
+    yield c
+    c.close()
+
+
+def assert_same(got, want, mode, W, what):
+    S = 20 if mode >= O.RGB_ASCII else 12
+    assert np.array_equal(got, want), "%s: %s" % (what, U.first_diff(got, want, S, W))
+
+
+KERNELS = ["brute", "binned"]
+
+
+def set_kernel(R, ctx, kernel, tile=0):
+    ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[kernel])
+    ctx.set_option(R.OPT_TILE_LOG2_W, tile)
+
+
+# ---------------------------------------------------------------- reference default scene
+
+SURVEY_8C_400x150 = {O.BIT_ASCII: "566f369b48c48349", O.BIT_PIXEL: "2600c441a058a41f", O.RGB_ASCII: "dd3497ccdb38ff6e",
+                     O.RGB_PIXEL: "08bda1486917bf70"}
+SURVEY_8C_1080P = {O.BIT_ASCII: "b366f64565c06fa1", O.BIT_PIXEL: "454b2ee3b30179c4", O.RGB_ASCII: "71e4385fd8fe0844",
+                   O.RGB_PIXEL: "0cef41476e6725c5"}
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("mode", range(5))
+@pytest.mark.parametrize("res", [(400, 150), (1920, 1080)])
+def test_default_scene_matches_oracle_and_survey_hash(R, ctx, res, mode, kernel):
+    w, h = res
+    set_kernel(R, ctx, kernel)
+    ctx.set_reference_default_scene()
+    p = R.camera_params(w, h)
+    got = ctx.render_to_host(p, mode)
+    want = O.render(U.oracle_params(p), O.Scene.reference_default(), mode, threads=8)
+    assert_same(got, want, mode, w, "default scene %dx%d %s %s" % (w, h, O.MODE_NAMES[mode], kernel))
+    known = (SURVEY_8C_400x150 if res == (400, 150) else SURVEY_8C_1080P).get(mode)
+    if known:  # the reference's own known answers (RGB_NORMALS excluded: they used the x86 conversion)
+        assert O.fnv1a64(got, O.FNV_OFFSET_SURVEY) == known
+
+
+# ---------------------------------------------------------------- BASELINE configs
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("mode", range(5))
+def test_c1_all_modes(R, ctx, mode, kernel):
+    set_kernel(R, ctx, kernel)
+    p, sph, pl = R.config_inputs("C1")
+    ctx.set_scene(sph, pl)
+    got = ctx.render_to_host(p, mode)
+    want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), mode)
+    assert_same(got, want, mode, int(p.x), "C1 %s %s" % (O.MODE_NAMES[mode], kernel))
+    assert O.fnv1a64(got) == U.load_golden()["C1_%s" % O.MODE_NAMES[mode]]["frame_fnv1a64"]
+
+
+def test_c1_against_committed_frame(R, ctx):
+    set_kernel(R, ctx, "auto")
+    p, sph, pl = R.config_inputs("C1")
+    ctx.set_scene(sph, pl)
+    got = ctx.render_to_host(p, R.RGB_ASCII)
+    want = np.load(os.path.join(U.GOLDEN_DIR, "c1_rgb_ascii_frame.npz"))["frame"]
+    assert_same(got, want, R.RGB_ASCII, int(p.x), "C1 frame fixture")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("mode", [O.BIT_ASCII, O.RGB_ASCII])
+def test_c2_full_size(R, ctx, mode, kernel):
+    set_kernel(R, ctx, kernel)
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    got = ctx.render_to_host(p, mode)
+    gold = U.load_golden()["C2_%s" % O.MODE_NAMES[mode]]
+    if O.fnv1a64(got) != gold["frame_fnv1a64"]:
+        want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), mode, threads=16)
+        assert_same(got, want, mode, int(p.x), "C2 %s %s" % (O.MODE_NAMES[mode], kernel))
+        pytest.fail("frame equals the oracle but not the committed golden hash")
+    W, H = int(p.x), int(p.y)
+    rec = got[:(20 if mode >= 2 else 12) * W * H].reshape(H, W, -1)
+    assert int((rec[:, :W - 1, 2] == ord("3")).sum()) == gold["foreground_pixels"]
+
+
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_large_configs_against_golden_hash(R, ctx, name):
+    gold = U.load_golden().get("%s_RGB_ASCII" % name)
+    if gold is None:
+        pytest.skip("golden for %s not generated (make_golden.py --big)" % name)
+    set_kernel(R, ctx, "auto")
+    p, sph, pl = R.config_inputs(name)
+    ctx.set_scene(sph, pl)
+    got = ctx.render_to_host(p, R.RGB_ASCII)
+    assert O.fnv1a64(got) == gold["frame_fnv1a64"]
+
+
+def test_c3_brute_equals_binned(R, ctx):
+    p, sph, pl = R.config_inputs("C3")
+    ctx.set_scene(sph, pl)
+    set_kernel(R, ctx, "brute")
+    a = ctx.render_to_host(p, R.RGB_ASCII)
+    set_kernel(R, ctx, "binned")
+    b = ctx.render_to_host(p, R.RGB_ASCII)
+    assert_same(b, a, R.RGB_ASCII, int(p.x), "C3 binned vs brute")
+
+
+# ---------------------------------------------------------------- properties and edge cases
+
+@pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
+def test_every_tile_shape_gives_the_same_frame(R, ctx, tile):
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    set_kernel(R, ctx, "binned", tile)
+    got = ctx.render_to_host(p, R.RGB_ASCII)
+    assert O.fnv1a64(got) == U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+
+
+def test_row_slabs_assemble_to_the_full_frame(R, ctx):
+    """rendering row slabs (global row index in ray generation) into one
+    buffer equals the one-launch frame, for 1/2/4/8-way splits and a ragged one."""
+    import torch
+    set_kernel(R, ctx, "auto")
+    p, sph, pl = R.config_inputs("C1")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    full = ctx.render_to_host(p, R.RGB_ASCII)
+    for parts in (1, 2, 4, 8, 7):
+        # full-frame destination
+        dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+        bounds = [H * i // parts for i in range(parts + 1)]
+        for i in range(parts):
+            ctx.render_rows(p, R.RGB_ASCII, bounds[i], bounds[i + 1] - bounds[i], d_out=dst.data_ptr(), out_row_base=0)
+        ctx.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), full), "parts=%d" % parts
+        # slab-local destinations, concatenated (what each rank holds before the gather)
+        pieces = []
+        for i in range(parts):
+            rows = bounds[i + 1] - bounds[i]
+            slab = torch.zeros(20 * W * rows, dtype=torch.uint8, device="cuda")
+            ctx.render_rows(p, R.RGB_ASCII, bounds[i], rows, d_out=slab.data_ptr(), out_row_base=bounds[i])
+            ctx.synchronize()
+            pieces.append(slab.cpu().numpy())
+        assert np.array_equal(np.concatenate(pieces), full), "slabs parts=%d" % parts
+
+
+def test_mode_switch_leaves_reference_zero_semantics(R, ctx):
+    """RGB frame, then an 8-bit frame in the same buffer: bytes past 12*W*H must read as zero, as after
+    the reference's per-frame memset (RayTracingManager.cu:86)."""
+    set_kernel(R, ctx, "auto")
+    ctx.set_reference_default_scene()
+    p = R.camera_params(400, 150)
+    ctx.render_to_host(p, R.RGB_PIXEL)
+    got = ctx.render_to_host(p, R.BIT_PIXEL)
+    want = O.render(U.oracle_params(p), O.Scene.reference_default(), O.BIT_PIXEL)
+    assert_same(got, want, O.BIT_PIXEL, 400, "8-bit after RGB")
+    # smaller frame after a larger one
+    p2 = R.camera_params(200, 75)
+    got2 = ctx.render_to_host(p2, R.BIT_ASCII)
+    want2 = O.render(U.oracle_params(p2), O.Scene.reference_default(), O.BIT_ASCII)
+    assert_same(got2, want2, O.BIT_ASCII, 200, "smaller 8-bit frame")
+
+
+def test_sdl_mode_writes_nothing(R, ctx):
+    import torch
+    ctx.set_reference_default_scene()
+    p = R.camera_params(64, 32)
+    dst = torch.full((20 * 64 * 32,), 7, dtype=torch.uint8, device="cuda")
+    ctx.render_rows(p, R.SDL, 0, 32, d_out=dst.data_ptr())
+    ctx.synchronize()
+    assert bool((dst == 7).all())
+
+
+def test_invalid_mode_and_arguments_are_reported(R, ctx):
+    p = R.camera_params(64, 32)
+    with pytest.raises(R.RtxError) as e:
+        ctx.render(p, 6)
+    assert e.value.status == R.ERR_INVALID_MODE
+    with pytest.raises(R.RtxError) as e:
+        ctx.render(p, -1)
+    assert e.value.status == R.ERR_INVALID_MODE
+    big = R.camera_params(4000, 4000)
+    with pytest.raises(R.RtxError) as e:
+        ctx.render(big, R.RGB_ASCII)
+    assert e.value.status == R.ERR_TOO_LARGE
+
+
+def test_empty_scene_and_tiny_frames(R, ctx):
+    set_kernel(R, ctx, "auto")
+    ctx.scene_clear()
+    for (w, h) in ((1, 1), (1, 5), (2, 1), (3, 3), (65, 5), (17, 33)):
+        p = R.camera_params(w, h)
+        for mode in (R.BIT_ASCII, R.RGB_ASCII):
+            got = ctx.render_to_host(p, mode)
+            want = O.render(U.oracle_params(p), O.Scene(), mode)
+            assert_same(got, want, mode, w, "empty scene %dx%d" % (w, h))
+    ctx.set_reference_default_scene()
+    for (w, h) in ((1, 1), (2, 2), (63, 3), (64, 4), (65, 5), (129, 31)):
+        p = R.camera_params(w, h)
+        for kernel in KERNELS:
+            set_kernel(R, ctx, kernel)
+            got = ctx.render_to_host(p, R.RGB_ASCII)
+            want = O.render(U.oracle_params(p), O.Scene.reference_default(), O.RGB_ASCII)
+            assert_same(got, want, O.RGB_ASCII, w, "default scene %dx%d %s" % (w, h, kernel))
+
+
+def test_interleaved_creation_order_breaks_ties_like_the_reference(R, ctx):
+    """Coincident objects: the earliest created one wins (strict '<' in creation order,
+    RayTracing.cu:123), whether it is a sphere or a plane."""
+    p = R.camera_params(160, 60)
+    for order in ("ssp", "pss", "sps"):
+        ctx.scene_clear()
+        sc = O.Scene()
+        si = 0
+        for ch in order:
+            if ch == "s":
+                col = [(250.0, 10.0, 10.0), (10.0, 250.0, 10.0)][si]
+                si += 1
+                ctx.add_sphere(6.0, (0.0, 0.0, 30.0), col)
+                sc.add_sphere(6.0, (0.0, 0.0, 30.0), col)
+            else:
+                ctx.add_plane((0.0, -2.0, 30.0), (0.0, 1.0, 0.0), (90.0, 90.0, 200.0), 30.0, 30.0)
+                sc.add_plane((0.0, -2.0, 30.0), (0.0, 1.0, 0.0), (90.0, 90.0, 200.0), 30.0, 30.0)
+        for kernel in KERNELS:
+            set_kernel(R, ctx, kernel)
+            got = ctx.render_to_host(p, R.RGB_PIXEL)
+            want = O.render(U.oracle_params(p), sc, O.RGB_PIXEL)
+            assert_same(got, want, O.RGB_PIXEL, 160, "order %s %s" % (order, kernel))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
+    """Randomised stress of the culling margin: tiny and huge spheres, spheres around and behind the
+    camera, a camera inside spheres, far-away origins, arbitrary poses."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = [(257, 97), (400, 150), (320, 180), (191, 203), (640, 64), (96, 301)][seed]
+    pos = rng.uniform(-30, 30, 3) if seed % 2 else rng.uniform(-3000, 3000, 3)
+    rot = (rng.uniform(-1.2, 1.2), rng.uniform(0, 6.28), 0.0)
+    p = R.camera_params(w, h, [float(v) for v in pos], [float(v) for v in rot])
+    n = 700
+    centres = pos + rng.normal(0, 1, (n, 3)) * rng.choice([5.0, 40.0, 300.0], (n, 1))
+    radii = np.abs(rng.normal(0, 1, n)) * rng.choice([0.01, 0.5, 5.0, 60.0], n) + 1e-4
+    cols = np.floor(rng.uniform(1, 256, (n, 3)))
+    sph = np.concatenate([centres, radii[:, None], cols], axis=1).astype(np.float32)
+    pl = np.array([[pos[0], pos[1] - 8, pos[2], 0, 1, 0, 100, 120, 140, 400, 400],
+                   [pos[0], pos[1] + 50, pos[2], 0.2, -1, 0.1, 30, 200, 90, 300, 500]], dtype=np.float32)
+    ctx.set_scene(sph, pl)
+    sc = O.Scene.from_arrays(sph, pl)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
+    for kernel in KERNELS:
+        for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
+            set_kernel(R, ctx, kernel, tile)
+            got = ctx.render_to_host(p, R.RGB_ASCII)
+            assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d" % (seed, kernel, tile))
+
+
+def test_per_pixel_values_within_tolerance(R, ctx):
+    """Decodes colours back from the RGB records and compares them with the oracle's float colours:
+    the digits are the truncated floats, so |decoded - colour| < 1 and exact after truncation."""
+    set_kernel(R, ctx, "auto")
+    p, sph, pl = R.config_inputs("C1")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    got = ctx.render_to_host(p, R.RGB_PIXEL).reshape(H, W, 20)
+    _, px = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), O.RGB_PIXEL, want_pixels=True)
+    vis = px["distance"] <= p.cam_far
+    vis[:, -1] = False
+
+    def dec(d):
+        d = d.astype(np.int32)
+        return np.where(d[..., 0] > 0, d[..., 0] - 48, 0) * 100 + np.where(d[..., 1] > 0, d[..., 1] - 48, 0) * 10 + d[..., 2] - 48
+
+    for ch, off in ((0, 7), (1, 11), (2, 15)):
+        val = dec(got[..., off:off + 3])[vis]
+        want = np.trunc(px["color"][..., ch][vis]).astype(np.int32)
+        assert np.array_equal(val, want)
+        assert np.all(np.abs(val - px["color"][..., ch][vis]) <= 1.0 + TOL_REL * 255)

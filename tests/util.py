@@ -1,0 +1,96 @@
+"""Shared helpers for the parity tests: one set of inputs fed to both the oracle and the HIP path."""
+import importlib
+import json
+import os
+
+import numpy as np
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+_pkg = None
+
+
+def pkg():
+    """The product package (hyphenated directory name, hence importlib)."""
+    global _pkg
+    if _pkg is None:
+        _pkg = importlib.import_module("raytracing-in-windows-console_amd")
+    return _pkg
+
+
+def oracle_params(p):
+    """rtx_params (product struct) -> oracle params, field by field."""
+    return O.params_from_arrays(np.array(p.inv_v[:], dtype=np.float32).reshape(4, 4), p.cam_pos[:], p.x, p.y,
+                                p.element1, p.element2, p.cam_far)
+
+
+def product_params(inv_v, cam, w, h, e1, e2, far):
+    P = pkg().Params()
+    flat = np.asarray(inv_v, dtype=np.float32).reshape(16)
+    for i in range(16):
+        P.inv_v[i] = float(flat[i])
+    for i in range(3):
+        P.cam_pos[i] = float(cam[i])
+    P.x, P.y = int(w), int(h)
+    P.element1, P.element2, P.cam_far = float(e1), float(e2), float(far)
+    return P
+
+
+def load_golden():
+    with open(os.path.join(GOLDEN_DIR, "golden.json")) as f:
+        return json.load(f)
+
+
+def first_diff(a, b, S, W):
+    """Human-readable location of the first differing byte of two frames."""
+    a = np.asarray(a, dtype=np.uint8)
+    b = np.asarray(b, dtype=np.uint8)
+    if a.size != b.size:
+        return "sizes differ: %d vs %d" % (a.size, b.size)
+    idx = np.flatnonzero(a != b)
+    if idx.size == 0:
+        return "identical"
+    i = int(idx[0])
+    row, rem = divmod(i, S * W)
+    col, off = divmod(rem, S)
+    lo = (i // S) * S
+    return "%d differing bytes; first at byte %d (row %d col %d +%d): got %r want %r" % (
+        idx.size, i, row, col, off, bytes(a[lo:lo + S]), bytes(b[lo:lo + S]))
+
+
+def numpy_synth_scene(seed, n_spheres, n_planes, e1, e2):
+    """Independent numpy-float32 implementation of SURVEY.md Appendix D (cross-checks rtx_synth_scene)."""
+    f = np.float32
+    e1, e2 = f(e1), f(e2)
+    state = [int(seed) & 0xffffffff]
+
+    def u01():
+        state[0] = (state[0] * 1664525 + 1013904223) & 0xffffffff
+        return f(state[0] >> 8) * f(2.0 ** -24)
+
+    def ur(a, b):
+        return f(a) + (f(b) - f(a)) * u01()
+
+    k = np.sqrt(f(1.4) * e1 * e2 / f(n_spheres)) if n_spheres else f(0)
+    sph = np.zeros((n_spheres, 7), dtype=np.float32)
+    for i in range(n_spheres):
+        d = ur(40, 200)
+        tx = e1 * ur(-0.95, 0.95)
+        ty = e2 * ur(-0.95, 0.95)
+        c = f(1) / np.sqrt(f(1) + tx * tx + ty * ty)
+        rr = d * k * ur(0.5, 1.0) * c * np.sqrt(c)
+        col = [np.floor(ur(1, 256)) for _ in range(3)]
+        sph[i] = [d * c * tx, d * c * ty, d * c, rr] + col
+    w2 = f(2) * e1 * f(250)
+    planes = np.array([
+        [0, -30, 125, 0, 1, 0, 100, 100, 100, w2, 250],
+        [0, 30, 125, 0, -1, 0, 60, 90, 160, w2, 250],
+        [0, 0, 220, 0, 0, -1, 150, 120, 90, w2, 1],
+        [f(-0.8) * e1 * f(200), 0, 125, 1, 0, 0, 160, 60, 60, 1, 250],
+        [f(0.8) * e1 * f(200), 0, 125, -1, 0, 0, 60, 160, 60, 1, 250],
+        [0, -6, 80, 0, 1, 0, 200, 200, 40, e1 * f(60), 30],
+    ], dtype=np.float32)
+    return sph, planes[:n_planes].copy()

@@ -26,6 +26,9 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden; only this header's entry points are exported */
+#pragma GCC visibility push(default)
+
 typedef struct rtx_ctx rtx_ctx;
 
 /* Status codes. */
@@ -171,6 +174,8 @@ int rtx_camera_params(size_t w, size_t h, const float pos[3], const float rot[3]
  * (cx cy cz r R G B) and n_planes*11 floats (px py pz nx ny nz R G B w h), n_planes <= 6. */
 int rtx_synth_scene(uint32_t seed, size_t n_spheres, size_t n_planes, float element1, float element2,
                     float* spheres_out, float* planes_out);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

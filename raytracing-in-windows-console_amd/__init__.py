@@ -93,6 +93,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                                "This package has no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch ships its own libamdhip64 (SONAME libamdhip64.so.7).
+        # Loading it first makes this library's DT_NEEDED libamdhip64.so.7 resolve to that same copy;
+        # the other order would put two runtimes in the process and the second one sees no GPU.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, restype, argtypes in _SIGNATURES:
             fn = getattr(L, name)  # AttributeError if the .so lacks a symbol the header declares

@@ -1,0 +1,62 @@
+// rtx_ctx.h -- the context behind the C ABI, shared by rtx_api.cpp and rtx_post.hip.
+#pragma once
+
+#include "../../include/rtx.h"
+#include "rtx_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+struct DeviceArray {
+    void* p = nullptr;
+    size_t cap = 0; // elements
+};
+
+struct HostPlane {
+    float4 a, b, c;
+};
+
+struct rtx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    size_t max_w = 0, max_h = 0, capacity = 0;
+    uint8_t* d_frame = nullptr;
+    uint8_t* d_min = nullptr;       // minimise output (allocated on first use)
+    void* d_scan = nullptr;         // minimise scratch
+    size_t scan_bytes = 0;
+    uint8_t* d_grey = nullptr;
+    size_t dirty_hi = 0;            // bytes of d_frame that may be non-zero
+
+    // scene: host staging for objects not yet uploaded + device SoA (the device copy is the truth
+    // once uploaded, because UpdateObjects moves spheres there)
+    std::vector<float4> h_sph_geom, h_sph_color, h_sph_motion;
+    std::vector<HostPlane> h_planes;
+    uint32_t ns = 0, np = 0, next_gidx = 0;
+    uint32_t ns_uploaded = 0, np_uploaded = 0;
+    DeviceArray d_sph_geom, d_sph_color, d_sph_motion, d_pl_a, d_pl_b, d_pl_c;
+    std::vector<uint8_t> kind_of;   // per creation index: 1 plane, 2 sphere (Object3D.h:14)
+    std::vector<uint32_t> local_of; // per creation index: index within its kind
+
+    int64_t opt_kernel = RTX_KERNEL_AUTO;
+    int64_t opt_tile_log2w = 0;
+
+    std::string error;
+    const char* last_kernel = "";
+};
+
+
+// rtx_api.cpp
+int rtx_fail(rtx_ctx* ctx, int status, const std::string& msg);
+int rtx_hip_fail(rtx_ctx* ctx, hipError_t e, const char* what);
+int rtx_sync_scene(rtx_ctx* ctx);
+
+#define RTX_HIP(ctx, call)                          \
+    do {                                            \
+        hipError_t e__ = (call);                    \
+        if (e__ != hipSuccess) {                    \
+            return rtx_hip_fail((ctx), e__, #call); \
+        }                                           \
+    } while (0)

@@ -1,0 +1,143 @@
+"""GPU Minimize, UpdateObjects and the whole-Update call against the oracle
+(RayTracingManager.cu:10-44, 76-154, 167-319)."""
+import numpy as np
+import pytest
+
+import oracle as O
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    return U.pkg()
+
+
+@pytest.fixture(scope="module")
+def ctx(R):
+    c = R.Context(1920, 1080)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("mode", range(5))
+@pytest.mark.parametrize("res", [(400, 150), (97, 41)])
+def test_minimize_matches_oracle_default_scene(R, ctx, res, mode):
+    import torch
+    w, h = res
+    ctx.set_reference_default_scene()
+    p = R.camera_params(w, h)
+    ctx.render(p, mode)
+    dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    n = ctx.minimize(mode, w, h, d_out=dst.data_ptr())
+    frame = ctx.read_frame(20 * w * h)
+    want = O.minimize(mode, frame, w, h)
+    got = dst.cpu().numpy()[:n]
+    assert n == want.size
+    assert np.array_equal(got, want)
+
+
+def test_minimize_c2_full_size_against_golden(R, ctx):
+    import torch
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    for mode in (R.RGB_ASCII, R.BIT_ASCII):
+        ctx.render(p, mode)
+        dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+        n = ctx.minimize(mode, W, H, d_out=dst.data_ptr())
+        g = gold["C2_%s" % R.MODE_NAMES[mode]]
+        assert n == g["minimized_bytes"]
+        assert O.fnv1a64(dst.cpu().numpy()[:n]) == g["minimized_fnv1a64"]
+
+
+def test_minimize_sdl_and_empty_rows(R, ctx):
+    import torch
+    w, h = 64, 9
+    ctx.set_reference_default_scene()
+    p = R.camera_params(w, h)
+    # SDL: nothing is written, the minimised stream is one newline per row
+    ctx.render(p, R.RGB_ASCII)
+    ctx.render(p, R.SDL)
+    dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    n = ctx.minimize(R.SDL, w, h, d_out=dst.data_ptr())
+    assert bytes(dst.cpu().numpy()[:n]) == b"\n" * h
+    # a frame with only some rows rendered (others NUL): colour persistence skips the empty rows
+    frame = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    ctx.render_rows(p, R.RGB_PIXEL, 2, 2, d_out=frame.data_ptr(), out_row_base=0)
+    ctx.render_rows(p, R.RGB_PIXEL, 6, 1, d_out=frame.data_ptr(), out_row_base=0)
+    ctx.synchronize()
+    n = ctx.minimize(R.RGB_PIXEL, w, h, d_in=frame.data_ptr(), d_out=dst.data_ptr())
+    want = O.minimize(O.RGB_PIXEL, frame.cpu().numpy(), w, h)
+    assert np.array_equal(dst.cpu().numpy()[:n], want)
+
+
+def test_minimize_width_one_and_two(R, ctx):
+    import torch
+    ctx.set_reference_default_scene()
+    for (w, h) in ((1, 5), (2, 7), (3, 3)):
+        p = R.camera_params(w, h)
+        ctx.render(p, R.BIT_ASCII)
+        dst = torch.zeros(20 * w * h + 4, dtype=torch.uint8, device="cuda")
+        n = ctx.minimize(R.BIT_ASCII, w, h, d_out=dst.data_ptr())
+        want = O.minimize(O.BIT_ASCII, ctx.read_frame(20 * w * h), w, h)
+        assert np.array_equal(dst.cpu().numpy()[:n], want)
+
+
+def test_update_is_the_reference_update(R, ctx):
+    """rtx_update = params, zero semantics, trace, minimise, copy: the bytes the reference hands to
+    PrintMachine::SetDataInBackBuffer (RayTracingManager.cu:150)."""
+    ctx.set_reference_default_scene()
+    p = R.camera_params(400, 150)
+    for mode in (R.BIT_ASCII, R.RGB_ASCII, R.RGB_NORMALS, R.BIT_PIXEL):
+        got = ctx.update(p, mode)
+        frame = O.render(U.oracle_params(p), O.Scene.reference_default(), mode)
+        want = O.minimize(mode, frame, 400, 150)
+        assert np.array_equal(got, want), R.MODE_NAMES[mode]
+
+
+def test_update_objects_matches_oracle_over_many_steps(R, ctx):
+    """Sphere::Update (Sphere.cu:15-23) with double dt, through several bounces; 1500 spheres so the
+    launch shape that breaks the reference past 1024 objects is exercised."""
+    rng = np.random.default_rng(7)
+    n = 1500
+    sph = np.concatenate([rng.uniform(-40, 40, (n, 3)), rng.uniform(0.5, 3, (n, 1)), np.floor(rng.uniform(1, 256, (n, 3)))],
+                         axis=1).astype(np.float32)
+    ctx.set_scene(sph, np.zeros((0, 11), dtype=np.float32))
+    ctx.add_plane((0.0, -3.0, 30.0), (0.0, 1.0, 0.0), (100.0, 100.0, 100.0), 10.0, 20.0)
+    sc = O.Scene.from_arrays(sph, np.zeros((0, 11), dtype=np.float32))
+    sc.add_plane((0.0, -3.0, 30.0), (0.0, 1.0, 0.0), (100.0, 100.0, 100.0), 10, 20)
+    speeds = (rng.integers(100, 400, n) / 100.0).astype(np.float32)  # Sphere.cu:11-12: (rand() % 300 + 100) / 100
+    for i in range(n):
+        ctx.set_sphere_motion(i, -1, float(speeds[i]))
+        sc.objects()[i].speed = float(speeds[i])
+        sc.objects()[i].mover = -1
+    for dt in (0.016, 0.25, 1.7, 0.0333333, 3.0, 0.5, 0.016):
+        ctx.update_objects(dt)
+        O.lib().orc_update_objects(sc.ptrs(), sc.count, dt)
+    for i in list(range(0, n, 37)) + [n - 1]:
+        t, v = ctx.get_object(i)
+        o = sc.objects()[i]
+        assert t == 2
+        assert v[1] == np.float32(o.center.y) and int(v[7]) == o.mover, i
+    t, v = ctx.get_object(n)
+    assert t == 1 and v[1] == -3.0
+    # and the frame after physics equals the oracle's frame of the moved scene
+    p = R.camera_params(200, 75)
+    got = ctx.render_to_host(p, R.RGB_ASCII)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=4)
+    assert np.array_equal(got, want)
+
+
+def test_update_with_physics_default_scene(R, ctx):
+    ctx.set_reference_default_scene()
+    sc = O.Scene.reference_default()
+    p = R.camera_params(400, 150)
+    for k in range(3):
+        got = ctx.update(p, R.RGB_ASCII, dt=0.05, run_physics=True)
+        O.lib().orc_update_objects(sc.ptrs(), sc.count, 0.05)
+        frame = O.render(U.oracle_params(p), sc, O.RGB_ASCII)
+        want = O.minimize(O.RGB_ASCII, frame, 400, 150)
+        assert np.array_equal(got, want), k

@@ -141,3 +141,24 @@ def test_update_with_physics_default_scene(R, ctx):
         frame = O.render(U.oracle_params(p), sc, O.RGB_ASCII)
         want = O.minimize(O.RGB_ASCII, frame, 400, 150)
         assert np.array_equal(got, want), k
+
+
+def test_reference_api_surface_end_to_end(R, tmp_path):
+    """examples/headless_engine.cpp drives the path through the reference's own class names
+    (RayTracingManager, Scene3D, Camera3D, PrintMachine over include/rtx_compat.hpp), three frames with
+    physics; its back buffer must be what the oracle's Update sequence produces."""
+    import os
+    import subprocess
+    exe = os.path.join(R.PKG_DIR, "headless_engine")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    out = tmp_path / "frame.bin"
+    for mode, frames, dt in ((R.BIT_ASCII, 3, 0.05), (R.RGB_ASCII, 2, 0.25)):
+        subprocess.check_call([exe, "400", "150", str(frames), str(mode), str(dt), str(out)])
+        got = np.fromfile(out, dtype=np.uint8)
+        sc = O.Scene.reference_default()
+        p = O.camera_params(400, 150)
+        for _ in range(frames):
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, dt)
+            frame = O.render(p, sc, mode)
+        want = O.minimize(mode, frame, 400, 150)
+        assert np.array_equal(got, want)

@@ -84,6 +84,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     R = importlib.import_module("raytracing-in-windows-console_amd")
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
     mode = R.MODE_NAMES.index(args.mode)
     S = R.SIZE_RGB if mode >= R.RGB_ASCII else R.SIZE_8BIT
     W, H, ns, npl, seed = R.CONFIGS[args.config]
@@ -95,7 +96,7 @@ def main():
     ctx.set_option(R.OPT_TILE_LOG2_W, args.tile)
 
     K, Wm = args.steps, args.warmup
-    bounds = [H * g // world for g in range(world + 1)]
+    bounds = sharding.row_bounds(H, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
     frame_bytes = 20 * W * H
 
@@ -129,27 +130,23 @@ def main():
         def step(i):
             b = i % nbuf
             if pending[b] is not None:      # the transfer that last used this buffer
-                for r in pending[b]:
-                    r.wait()
+                sharding.wait_all(pending[b])
                 pending[b] = None
             if rank == 0:
                 # root traces its own rows straight into the frame and receives every peer's slab at
                 # that peer's byte offset (row-major rows: a slab is one contiguous range)
                 ctx.render_rows(params, mode, row0, rows, d_out=frames[b].data_ptr(), out_row_base=0,
                                 stream=stream.cuda_stream)
-                ops = [dist.P2POp(dist.irecv, frames[b][S * W * bounds[g]: S * W * bounds[g + 1]], g)
-                       for g in range(1, world)]
+                pending[b] = sharding.post_gather(dist, rank, world, bounds, W, S, root_frame=frames[b])
             else:
                 ctx.render_rows(params, mode, row0, rows, d_out=slabs[b].data_ptr(), out_row_base=row0,
                                 stream=stream.cuda_stream)
-                ops = [dist.P2POp(dist.isend, slabs[b], 0)]
-            pending[b] = dist.batch_isend_irecv(ops) if ops else None
+                pending[b] = sharding.post_gather(dist, rank, world, bounds, W, S, slab=slabs[b])
 
         def drain():
             for b in range(nbuf):
                 if pending[b] is not None:
-                    for r in pending[b]:
-                        r.wait()
+                    sharding.wait_all(pending[b])
                     pending[b] = None
 
         for i in range(Wm):

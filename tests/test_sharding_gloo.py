@@ -1,0 +1,74 @@
+"""The N > 1 path on CPU: world_size 2 and 3 over gloo.  Each rank produces its row slab (here with the
+oracle, since there is no GPU) and the frame is assembled on rank 0 with the same exchange code
+bench.py runs over RCCL; the assembled frame must equal the one-piece frame byte for byte."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+import util as U
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, mode, out_path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import importlib
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
+    R = U.pkg()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        p, sph, pl = R.config_inputs("C1")
+        W, H = int(p.x), int(p.y)
+        S = 20 if mode >= O.RGB_ASCII else 12
+        sc = O.Scene.from_arrays(sph, pl)
+        op = U.oracle_params(p)
+        bounds = sharding.row_bounds(H, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        full = O.render(op, sc, mode, row0=r0, rows=r1 - r0)  # only this rank's rows are non-zero
+        for it in range(2):  # two frames, as the double-buffered bench loop does
+            if rank == 0:
+                frame = torch.from_numpy(full.copy())
+                reqs = sharding.post_gather(dist, rank, world, bounds, W, S, root_frame=frame)
+            else:
+                slab = torch.from_numpy(full[r0 * W * S: r1 * W * S].copy())
+                assert slab.numel() == sharding.slab_bytes(bounds, rank, W, S)
+                reqs = sharding.post_gather(dist, rank, world, bounds, W, S, slab=slab)
+            sharding.wait_all(reqs)
+        dist.barrier()
+        if rank == 0:
+            want = O.render(op, sc, mode)
+            np.save(out_path, np.array([int(np.array_equal(frame.numpy(), want))]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, O.RGB_ASCII), (2, O.BIT_ASCII), (3, O.RGB_PIXEL)])
+def test_row_sharded_frame_assembles_on_rank0(tmp_path, world, mode):
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
+    assert int(np.load(out)[0]) == 1
+
+
+def test_row_bounds_cover_every_row_once():
+    import importlib
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
+    for H in (1, 7, 180, 1080, 4320):
+        for world in (1, 2, 3, 4, 8):
+            b = sharding.row_bounds(H, world)
+            assert b[0] == 0 and b[-1] == H and all(b[i] <= b[i + 1] for i in range(world))

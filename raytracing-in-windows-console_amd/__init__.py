@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librtx_hip.so")
+LIB_PATH = os.path.join(PKG_DIR, os.environ.get("RTX_LIB", "librtx_hip.so"))  # RTX_LIB: experiment builds only
 
 # enum rtx_mode == enum RenderingMode (RayTracingManager.h:21)
 BIT_ASCII, BIT_PIXEL, RGB_ASCII, RGB_PIXEL, RGB_NORMALS, SDL = range(6)
@@ -24,7 +24,7 @@ SIZE_8BIT, SIZE_RGB = 12, 20
 
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_TOO_LARGE = range(7)
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
-OPT_KERNEL, OPT_TILE_LOG2_W = 1, 2
+OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES = 1, 2, 3
 RENDER_ZERO_TAIL = 1
 
 

@@ -15,7 +15,7 @@ struct DeviceArray {
 };
 
 struct HostPlane {
-    float4 a, b, c;
+    float4 a, b, c, od;
 };
 
 struct rtx_ctx {
@@ -32,16 +32,17 @@ struct rtx_ctx {
 
     // scene: host staging for objects not yet uploaded + device SoA (the device copy is the truth
     // once uploaded, because UpdateObjects moves spheres there)
-    std::vector<float4> h_sph_geom, h_sph_color, h_sph_motion;
+    std::vector<float4> h_sph_geom, h_sph_color, h_sph_od, h_sph_motion;
     std::vector<HostPlane> h_planes;
     uint32_t ns = 0, np = 0, next_gidx = 0;
     uint32_t ns_uploaded = 0, np_uploaded = 0;
-    DeviceArray d_sph_geom, d_sph_color, d_sph_motion, d_pl_a, d_pl_b, d_pl_c;
+    DeviceArray d_sph_geom, d_sph_color, d_sph_od, d_sph_motion, d_pl_a, d_pl_b, d_pl_c, d_pl_od;
     std::vector<uint8_t> kind_of;   // per creation index: 1 plane, 2 sphere (Object3D.h:14)
     std::vector<uint32_t> local_of; // per creation index: index within its kind
 
     int64_t opt_kernel = RTX_KERNEL_AUTO;
     int64_t opt_tile_log2w = 0;
+    int64_t opt_subtiles = 0;
 
     std::string error;
     const char* last_kernel = "";

@@ -22,10 +22,51 @@ __device__ __forceinline__ V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, 
 __device__ __forceinline__ V3 mulf(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
 // MyMath.cu:5-8: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// ---- correctly rounded 1.0f/x and sqrtf(x) in fewer instructions than hipcc's generic expansions.
+//
+// The path needs the IEEE results bit for bit.  hipcc expands 1.0f/x into v_div_scale x2, v_rcp,
+// six FMAs/fmas and v_div_fixup, and sqrtf into v_sqrt plus a two-candidate residual test: about 10
+// and 16 instructions, most of them guarding ranges this path never visits.  Inside a wide safe
+// range the sequences below are shorter; outside it they fall back to the generic expansion.
+// Equality with the generic results is verified EXHAUSTIVELY, for all 2^32 inputs, on the GPU
+// (tests/gpu_checks/math_check.hip, tests/test_gpu_math.py): that test is the proof.
+constexpr float kSafeLo = 0x1.0p-60f, kSafeHi = 0x1.0p+60f;
+
+__device__ __forceinline__ float rcp_cr(float x)
+{
+    const float ax = fabsf(x);
+    if (ax >= kSafeLo && ax <= kSafeHi) {
+        // hardware estimate (1 ulp), one Newton step, then two residual corrections (Markstein)
+        float r = __builtin_amdgcn_rcpf(x);
+        const float e0 = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(e0, r, r);
+        const float e1 = __builtin_fmaf(-x, r, 1.0f);
+        return __builtin_fmaf(e1, r, r);
+    }
+    return 1.0f / x;
+}
+
+__device__ __forceinline__ float sqrt_cr(float x)
+{
+    if (x >= kSafeLo && x <= kSafeHi) {
+        // g ~ sqrt(x), h ~ 1/(2 sqrt(x)) from the hardware rsq, one coupled Newton step, then the
+        // exact residual x - g*g (one FMA) corrects g to the correctly rounded root
+        const float y = __builtin_amdgcn_rsqf(x);
+        float g = x * y;
+        float h = 0.5f * y;
+        const float r = __builtin_fmaf(-h, g, 0.5f);
+        g = __builtin_fmaf(g, r, g);
+        h = __builtin_fmaf(h, r, h);
+        const float d = __builtin_fmaf(-g, g, x);
+        return __builtin_fmaf(d, h, g);
+    }
+    return sqrtf(x);
+}
+
 // MyMath.h:139-145: one reciprocal, three multiplies, no zero check
 __device__ __forceinline__ V3 normalize_gpu(V3 a)
 {
-    const float length = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    const float length = rcp_cr(sqrt_cr(a.x * a.x + a.y * a.y + a.z * a.z));
     return v3(a.x * length, a.y * length, a.z * length);
 }
 // MyMath.cu:29-34
@@ -75,29 +116,6 @@ struct Camera {
     float fW, fH; // (float)W, (float)H
 };
 
-// CalculateInitialDirection, RayTracing.cu:9-24, and the per-ray constants of RayTracing.cu:91-93.
-__device__ __forceinline__ Ray make_ray(const Camera& c, uint32_t row, uint32_t col)
-{
-    const float convertedY = (c.fH - (float)(row * 2u)) / c.fH;
-    const float convertedX = ((float)(2u * col) - c.fW) / c.fW;
-    const float vx = convertedX * c.e1;
-    const float vy = convertedY * c.e2;
-    const float vz = 1.0f;
-    const float vw = 0.0f;
-    // Matrix::Mult, MyMath.h:310-319
-    V3 w;
-    w.x = c.m[0] * vx + c.m[1] * vy + c.m[2] * vz + c.m[3] * vw;
-    w.y = c.m[4] * vx + c.m[5] * vy + c.m[6] * vz + c.m[7] * vw;
-    w.z = c.m[8] * vx + c.m[9] * vy + c.m[10] * vz + c.m[11] * vw;
-    Ray r;
-    r.o = v3(c.ox, c.oy, c.oz);
-    r.d = normalize_gpu(w);
-    r.a = dot(r.d, r.d);
-    r.fourA = 4.0f * r.a;
-    r.divTwoA = 1.0f / (2.0f * r.a);
-    return r;
-}
-
 // Sphere::Trace, Sphere.cu:30-68, split in two.
 //
 // sphere_reject: the miss test on the hoisted terms otc = o - c and cc = Dot(otc,otc) - r*r
@@ -120,7 +138,7 @@ __device__ __forceinline__ bool sphere_hit(const Ray& r, float s, float cc, floa
     if (discriminant < 0.0f) {
         return false;
     }
-    const float sqrtDiscriminant = sqrtf(discriminant);
+    const float sqrtDiscriminant = sqrt_cr(discriminant);
     const float minusB = -b;
     const float t1 = (minusB + sqrtDiscriminant) * r.divTwoA;
     const float t2 = (minusB - sqrtDiscriminant) * r.divTwoA;
@@ -154,17 +172,17 @@ __device__ __forceinline__ bool plane_hit(const Ray& r, V3 p, V3 n, float width,
 }
 
 // BlinnPhongShading with the call-site constants, RayTracing.cu:41-79 and :143-157.
-// colour in: object colour (0..255 floats); out: shaded colour clamped to <= 255.
-__device__ __forceinline__ V3 shade(const Ray& r, float distance, V3 normal, V3 objColour)
+// od in: object colour / 255.0f (RayTracing.cu:144; the division is done once per object at upload,
+// the same IEEE operation on the same operands); out: shaded colour clamped to <= 255.
+__device__ __forceinline__ V3 shade(const Ray& r, float distance, V3 normal, V3 od)
 {
-    const V3 od = v3(objColour.x / 255.0f, objColour.y / 255.0f, objColour.z / 255.0f);
     const V3 point = add(r.o, mulf(r.d, distance));
     const V3 viewDir = normalize_gpu(mulf(r.d, -1.0f));
 
     V3 lightDir = sub(v3(1.0f, 50.0f, 0.0f), point);
-    float dist = sqrtf(lightDir.x * lightDir.x + lightDir.y * lightDir.y + lightDir.z * lightDir.z);
+    float dist = sqrt_cr(lightDir.x * lightDir.x + lightDir.y * lightDir.y + lightDir.z * lightDir.z);
     dist = dist * dist;
-    const float divDistance = 1.0f / dist;
+    const float divDistance = rcp_cr(dist);
     lightDir = normalize_gpu(lightDir);
 
     const V3 nn = normalize_gpu(normal);

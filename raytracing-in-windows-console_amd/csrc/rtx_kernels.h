@@ -25,21 +25,26 @@ struct KArgs {
     uint32_t row0, row_end;   // rows traced by this launch (global row indices)
     uint32_t out_row_base;    // the row stored at out[0]
     uint32_t ns, np;          // spheres, planes
-    uint32_t tile_log2w;      // workgroup tile is 2^lw x 2^(8-lw) pixels
+    uint32_t tile_log2w;      // a sub-tile is 2^lw x 2^(8-lw) pixels (one pixel per thread)
+    uint32_t sub_log2nx;      // a workgroup's macro tile is 2^lnx sub-tiles wide, NSUB >> lnx high
     // Scene, SoA in HBM (creation order within each kind; .w of the colour arrays carries the
-    // creation index across kinds as uint bits):
+    // creation index across kinds as uint bits; the raw colours stay in host-visible arrays of the
+    // context for rtx_scene_get_object):
     const float4* sph_geom;   // cx cy cz r
-    const float4* sph_color;  // R G B gidx
+    const float4* sph_od;     // R/255 G/255 B/255 gidx  (RayTracing.cu:144: colour / 255.0f, hoisted to upload time)
     const float4* pl_a;       // px py pz width
     const float4* pl_b;       // nx ny nz height
-    const float4* pl_c;       // R G B gidx
+    const float4* pl_od;      // R/255 G/255 B/255 gidx
     const uint8_t* grey;      // 256-byte grey lookup of the xterm-256 mapper
     uint8_t* out;             // records of row out_row_base start here
+#ifdef RTX_ABLATE
+    uint32_t ablate;          // experiment builds only (make ablate): bit mask of stages to skip
+#endif
 };
 
 extern "C" {
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
-const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
+const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, int nsub, void* stream, int* hip_error);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 }

@@ -1,14 +1,16 @@
 // rtx_kernels.hip -- gfx950 kernels of the ray-trace hot path.
 //
-// One thread per pixel (as the reference, RayTracingManager.cu:120-125), 256-thread workgroups
-// over a 2^lw x 2^(8-lw) pixel tile.  Each workgroup walks the sphere array in chunks of 256
-// (coalesced float4 loads), hoists the ray-independent terms otc = o - c and
-// cc = Dot(otc,otc) - r*r (Sphere.cu:34-37), optionally culls spheres whose inflated bound
-// cannot touch the tile's frustum, and appends survivors to a candidate list in LDS.  When the
-// list fills (or the scene ends) every thread runs the reference's exact ray/sphere test over
-// the list (wave-uniform index, LDS broadcast reads).  Planes are tested from scalar loads.
-// The winner alone is shaded and encoded (the reference re-derives normal/colour on every
-// improving hit, RayTracing.cu:123-135, but only the last survives).
+// One thread per pixel per pass (as the reference, RayTracingManager.cu:120-125).  A 256-thread
+// workgroup owns a macro tile of NSUB sub-tiles, each 2^lw x 2^(8-lw) pixels, and handles one
+// sub-tile per pass.  Once per workgroup: the sphere array is walked in chunks of 256 (coalesced
+// float4 loads), the ray-independent terms otc = o - c and cc = Dot(otc,otc) - r*r are hoisted
+// (Sphere.cu:34-37), spheres whose inflated bound cannot touch the macro tile's pyramid are
+// culled (CULL), and survivors are appended in index order to a candidate list in LDS; the
+// per-column and per-row terms of ray generation and the decimal-digit table are staged in LDS
+// as well.  Then, per sub-tile, every thread runs the reference's exact ray/sphere test over the
+// list (wave-uniform index, LDS broadcast reads); planes are tested from scalar loads.  The
+// winner alone is shaded and encoded (the reference re-derives normal/colour on every improving
+// hit, RayTracing.cu:123-135, but only the last survives).
 //
 // Closest hit = lexicographic minimum of (t, creation index): the same object the reference's
 // in-order scan with strict '<' keeps (RayTracing.cu:123).
@@ -17,8 +19,17 @@
 
 namespace rtx {
 
+// Timing experiments only (make ablate -> librtx_hip_ablate.so, never shipped): ABL(bit) is true when
+// the stage is to be skipped.  In the product build it is the constant false.
+#ifdef RTX_ABLATE
+#define ABL(bit) ((a.ablate & (bit)) != 0u)
+#else
+#define ABL(bit) false
+#endif
+
 constexpr int kThreads = 256;
-constexpr int kListCap = 1024;     // candidate records per flush: 16 KiB + 4 KiB of LDS
+constexpr int kListCapBrute = 1024;  // candidate records per flush (brute: every sphere is a candidate)
+constexpr int kListCapCull = 512;    // culling kernels: lists are short; 10 KiB keeps 8 workgroups per CU
 constexpr float kNoHit = 99999999.f; // RayTracing.h:21
 
 // RayTracing.h:97-115 (68 glyphs).
@@ -53,16 +64,19 @@ __device__ __forceinline__ V3 view_dir(const Camera& c, float cx, float cy)
     return v3(c.m[0] * vx + c.m[1] * vy + c.m[2], c.m[4] * vx + c.m[5] * vy + c.m[6], c.m[8] * vx + c.m[9] * vy + c.m[10]);
 }
 
-// Side planes of the pyramid spanned by the tile's pixel centres, grown by half a pixel on every
-// side.  Pixel directions are linear in (cx, cy), so every pixel ray of the tile lies in the
-// convex cone of the four corner directions.  A normal that cannot be oriented (degenerate
-// matrix, NaN) becomes the zero vector, which never culls.
-__device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t col0, uint32_t row0, uint32_t tw, uint32_t th)
+// Side planes of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows
+// [row0, row0+h), grown by half a pixel on every side.  Pixel directions are linear in (cx, cy), so
+// every pixel ray of the tile lies in the convex cone of the four corner directions.  A normal
+// that cannot be oriented (degenerate matrix, NaN) becomes the zero vector, which never culls.
+// This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the
+// slack in tile_culls covers their error.
+__device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h)
 {
-    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) / c.fW;
-    const float x1 = (2.0f * (float)(col0 + tw) - 1.0f - c.fW) / c.fW;
-    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) / c.fH;        // top edge (larger cy)
-    const float y1 = (c.fH - 2.0f * (float)(row0 + th) + 1.0f) / c.fH;  // bottom edge
+    const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
+    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
+    const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
+    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;       // top edge (larger cy)
+    const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;  // bottom edge
     const V3 c00 = view_dir(c, x0, y0), c10 = view_dir(c, x1, y0), c11 = view_dir(c, x1, y1), c01 = view_dir(c, x0, y1);
     const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
     V3 raw[4] = {cross(c00, c10), cross(c10, c11), cross(c11, c01), cross(c01, c00)};
@@ -76,22 +90,22 @@ __device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t co
             side = -side;
         }
         const float len2 = dot(n, n);
-        if (side > 0.0f && len2 > 0.0f && len2 < 3.0e38f) {
-            f.n[k] = mulf(n, 1.0f / sqrtf(len2));
+        if (side > 0.0f && len2 > 1.0e-30f && len2 < 1.0e30f) {
+            f.n[k] = mulf(n, __builtin_amdgcn_rsqf(len2));
         } else {
             f.n[k] = v3(0.0f, 0.0f, 0.0f);
         }
     }
     const float alen2 = dot(axis, axis);
-    f.n[4] = (alen2 > 0.0f && alen2 < 3.0e38f) ? mulf(axis, 1.0f / sqrtf(alen2)) : v3(0.0f, 0.0f, 0.0f);
+    f.n[4] = (alen2 > 1.0e-30f && alen2 < 1.0e30f) ? mulf(axis, __builtin_amdgcn_rsqf(alen2)) : v3(0.0f, 0.0f, 0.0f);
     return f;
 }
 
 // true when the sphere (hoisted form) provably cannot be hit by any pixel ray of the tile.
 __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float oy, float oz, float oo, float r)
 {
-    // margin >= R + 3u|otc| + evaluation slack (see kKappa)
-    const float margin = r * (1.0f + kKappa) + kSqrtKappaPlusSlack * sqrtf(oo);
+    // margin >= R + 3u|otc| + evaluation slack (see kKappa); hardware sqrt is within 1 ulp
+    const float margin = r * (1.0f + kKappa) + kSqrtKappaPlusSlack * __builtin_amdgcn_sqrtf(oo);
     bool out = false;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -108,7 +122,7 @@ struct Best {
 };
 
 template <int MODE>
-__device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const Ray& ray, bool in_frame, bool is_newline_col,
+__device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const uint32_t* s_digits, bool in_frame, bool is_newline_col,
                                                  uint32_t row, uint32_t col, float distance, V3 normal, V3 colour, float shadingValue)
 {
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
@@ -140,7 +154,7 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
                 g = u8_sat(colour.y);
                 b = u8_sat(colour.z);
             }
-            const uint32_t dr = digits3(r), dg = digits3(g), db = digits3(b);
+            const uint32_t dr = s_digits[r], dg = s_digits[g], db = s_digits[b];
             const uint32_t kind = (MODE == RTX_K_RGB_ASCII) ? '3' : '4';
             const uint32_t glyph = (MODE == RTX_K_RGB_ASCII) ? (uint32_t)(uint8_t)kRamp[ramp_index(shadingValue)] : (uint32_t)' ';
             w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
@@ -165,7 +179,7 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
         uint32_t w0, w1, w2;
         if (visible) {
             const uint32_t index = ansi256_from_rgb(u8_sat(colour.x), u8_sat(colour.y), u8_sat(colour.z), a.grey);
-            const uint32_t d = digits3(index);
+            const uint32_t d = s_digits[index];
             const uint32_t kind = (MODE == RTX_K_BIT_ASCII) ? '3' : '4';
             const uint32_t glyph = (MODE == RTX_K_BIT_ASCII) ? (uint32_t)(uint8_t)kRamp[ramp_index(shadingValue)] : (uint32_t)' ';
             w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
@@ -183,20 +197,67 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
     }
 }
 
-template <int MODE, bool CULL>
+// Exact tests of one ray against the candidate list (index is wave-uniform: LDS broadcast reads).
+__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best)
+{
+    for (uint32_t i = 0; i < total; i++) {
+        const float4 sr = s_rec[i];
+        float s;
+        if (!sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s)) {
+            ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
+            float t;
+            if (sphere_hit(ray, s, sr.w, t)) {
+                const uint32_t ki = s_idx[i];
+                if (t < best.t || (t == best.t && ki < best.k)) {
+                    best.t = t;
+                    best.k = ki;
+                }
+            }
+        }
+    }
+}
+
+// Ray of pixel (row, col) from the staged per-column / per-row terms:
+//   A = (m0, m4, m8) * (convertedX * e1),  B = (m1, m5, m9) * (convertedY * e2)
+// so that d.k = ((A.k + B.k) + m[4k+2] * 1.0f) + m[4k+3] * 0.0f, the order of Matrix::Mult
+// (MyMath.h:310-319) applied to (vx, vy, 1, 0) as in RayTracing.cu:19-23.
+__device__ __forceinline__ Ray ray_from_tables(const Camera& c, float4 A, float4 B)
+{
+    V3 w;
+    w.x = ((A.x + B.x) + c.m[2]) + c.m[3] * 0.0f;
+    w.y = ((A.y + B.y) + c.m[6]) + c.m[7] * 0.0f;
+    w.z = ((A.z + B.z) + c.m[10]) + c.m[11] * 0.0f;
+    Ray r;
+    r.o = v3(c.ox, c.oy, c.oz);
+    r.d = normalize_gpu(w);
+    r.a = dot(r.d, r.d);
+    r.fourA = 4.0f * r.a;
+    r.divTwoA = 0.0f; // filled on the hit path only
+    return r;
+}
+
+constexpr int kMaxMacro = 128; // macro tile is at most 128 x 128 pixels
+
+template <int MODE, bool CULL, int NSUB>
 __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
 {
+    constexpr int kListCap = CULL ? kListCapCull : kListCapBrute;
     __shared__ float4 s_rec[kListCap];
     __shared__ uint32_t s_idx[kListCap];
-    __shared__ uint32_t s_wcnt[2][4]; // survivors per wave of the current chunk, double-buffered
+    __shared__ float4 s_col[kMaxMacro];  // per column: (m0, m4, m8) * vx
+    __shared__ float4 s_row[kMaxMacro];  // per row:    (m1, m5, m9) * vy
+    __shared__ uint32_t s_digits[256];   // three decimal digits of 0..255, NUL padded
+    __shared__ uint32_t s_wcnt[2][4];    // survivors per wave of the current chunk, double-buffered
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
     const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
-    const uint32_t col0 = blockIdx.x * tw;
-    const uint32_t row0 = a.row0 + blockIdx.y * th;
-    const uint32_t col = col0 + (tid & (tw - 1u));
-    const uint32_t row = row0 + (tid >> lw);
+    const uint32_t lnx = a.sub_log2nx;              // sub-tiles are laid out nx wide, NSUB/nx high
+    const uint32_t nx = 1u << lnx, ny = (uint32_t)NSUB >> lnx;
+    const uint32_t mw = tw * nx, mh = th * ny;      // macro tile, pixels
+    const uint32_t mcol0 = blockIdx.x * mw;
+    const uint32_t mrow0 = a.row0 + blockIdx.y * mh;
+    const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
 
     Camera cam;
 #pragma unroll
@@ -207,25 +268,38 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
     cam.fW = a.fW; cam.fH = a.fH;
 
-    const bool in_frame = col < a.W && row < a.row_end;
-    const bool newline_col = col + 1u == a.W;
-    // lanes outside the frame trace a clamped pixel so that every lane runs the same loops
-    const Ray ray = make_ray(cam, row < a.row_end ? row : a.row_end - 1u, col < a.W ? col : a.W - 1u);
+    // ---- per-workgroup tables (visible after the first barrier below)
+    s_digits[tid] = digits3(tid);
+    if (tid < mw) {
+        // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
+        const uint32_t c = mcol0 + tid < a.W ? mcol0 + tid : a.W - 1u;
+        const float vx = (((float)(2u * c) - cam.fW) / cam.fW) * cam.e1;
+        s_col[tid] = make_float4(cam.m[0] * vx, cam.m[4] * vx, cam.m[8] * vx, 0.0f);
+    } else if (tid - mw < mh) {
+        // convertedY = ((float)y - row * 2) / y;  vy = convertedY * element2   (RayTracing.cu:16,20)
+        const uint32_t rr = mrow0 + (tid - mw);
+        const uint32_t r = rr < a.row_end ? rr : a.row_end - 1u;
+        const float vy = ((cam.fH - (float)(r * 2u)) / cam.fH) * cam.e2;
+        s_row[tid - mw] = make_float4(cam.m[1] * vy, cam.m[5] * vy, cam.m[9] * vy, 0.0f);
+    }
 
     TileFrustum fr;
     if (CULL) {
-        fr = tile_frustum(cam, col0, row0, tw, th);
+        fr = tile_frustum(cam, mcol0, mrow0, mw, mh);
     }
 
-    Best best;
-    best.t = kNoHit;
-    best.k = 0xffffffffu;
+    Best best[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; j++) {
+        best[j].t = kNoHit;
+        best[j].k = 0xffffffffu;
+    }
 
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
     uint32_t total = 0; // candidates in the list; identical in every thread
     uint32_t parity = 0;
-    for (uint32_t base = 0; base < a.ns; base += kThreads, parity ^= 1u) {
+    for (uint32_t base = 0; base < (ABL(1u) ? 0u : a.ns); base += kThreads, parity ^= 1u) {
         // ---- stage one chunk: hoist, cull, append in index order
         const uint32_t k = base + tid;
         bool keep = false;
@@ -244,6 +318,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
                     keep = false;
                 }
             }
+            if (ABL(2u)) keep = false;
         }
         const unsigned long long m = __ballot(keep);
         if (lane == 0) {
@@ -259,79 +334,91 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         }
         total = __builtin_amdgcn_readfirstlane(total + c0 + c1 + c2 + c3);
         const bool last = base + kThreads >= a.ns;
-        if (total > (uint32_t)(kListCap - kThreads) || last) {
+        if (total > (uint32_t)(kListCap - kThreads) && !last) {
+            // ---- the list is full before the scene ends: fold it into every sub-tile's best hit
             __syncthreads();
-            // ---- exact tests over the candidate list (index is wave-uniform: LDS broadcast)
-            for (uint32_t i = 0; i < total; i++) {
-                const float4 sr = s_rec[i];
-                float s;
-                if (!sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s)) {
-                    float t;
-                    if (sphere_hit(ray, s, sr.w, t)) {
-                        const uint32_t ki = s_idx[i];
-                        if (t < best.t || (t == best.t && ki < best.k)) {
-                            best.t = t;
-                            best.k = ki;
-                        }
-                    }
-                }
+#pragma unroll
+            for (int j = 0; j < NSUB; j++) {
+                const uint32_t jx = (uint32_t)j & (nx - 1u), jy = (uint32_t)j >> lnx;
+                Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
+                scan_candidates(ray, s_rec, s_idx, total, best[j]);
             }
             total = 0;
         }
     }
+    __syncthreads(); // list complete (and tables visible when the scene has no spheres)
 
-    // ---- winner among spheres: creation index for the tie-break against planes
-    uint32_t best_gidx = 0xffffffffu;
-    float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wcol = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (best.k != 0xffffffffu) {
-        wgeom = a.sph_geom[best.k];
-        wcol = a.sph_color[best.k];
-        best_gidx = __float_as_uint(wcol.w);
-    }
+    // ---- one pass per sub-tile
+#pragma unroll
+    for (int j = 0; j < NSUB; j++) {
+        const uint32_t jx = (uint32_t)j & (nx - 1u), jy = (uint32_t)j >> lnx;
+        const uint32_t scol0 = mcol0 + jx * tw, srow0 = mrow0 + jy * th;
+        if (scol0 >= a.W || srow0 >= a.row_end) {
+            continue; // sub-tile entirely outside the frame (uniform)
+        }
+        const uint32_t col = scol0 + tx, row = srow0 + ty;
+        const bool in_frame = col < a.W && row < a.row_end;
+        const bool newline_col = col + 1u == a.W;
+        // lanes outside the frame trace a clamped pixel (the tables clamp) so every lane runs the same loops
+        Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
+        Best b = best[j];
+        if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
 
-    // ---- planes (few; wave-uniform index -> scalar loads)
-    bool plane_won = false;
-    V3 plane_n = v3(0.f, 0.f, 0.f), plane_col = v3(0.f, 0.f, 0.f);
-    for (uint32_t j = 0; j < a.np; j++) {
-        const float4 pa = a.pl_a[j]; // px py pz width
-        const float4 pb = a.pl_b[j]; // nx ny nz height
-        float t;
-        if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
-            const float4 pc = a.pl_c[j]; // R G B gidx
-            const uint32_t gi = __float_as_uint(pc.w);
-            if (t < best.t || (t == best.t && gi < best_gidx)) {
-                best.t = t;
-                best_gidx = gi;
-                plane_won = true;
-                plane_n = v3(pb.x, pb.y, pb.z);
-                plane_col = v3(pc.x, pc.y, pc.z);
+        // ---- winner among spheres: creation index for the tie-break against planes
+        uint32_t best_gidx = 0xffffffffu;
+        float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wod = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b.k != 0xffffffffu) {
+            wgeom = a.sph_geom[b.k];
+            wod = a.sph_od[b.k];
+            best_gidx = __float_as_uint(wod.w);
+        }
+
+        // ---- planes (few; wave-uniform index -> scalar loads)
+        bool plane_won = false;
+        V3 plane_n = v3(0.f, 0.f, 0.f), plane_od = v3(0.f, 0.f, 0.f);
+        for (uint32_t q = 0; q < (ABL(8u) ? 0u : a.np); q++) {
+            const float4 pa = a.pl_a[q]; // px py pz width
+            const float4 pb = a.pl_b[q]; // nx ny nz height
+            float t;
+            if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
+                const float4 pd = a.pl_od[q]; // R/255 G/255 B/255 gidx
+                const uint32_t gi = __float_as_uint(pd.w);
+                if (t < b.t || (t == b.t && gi < best_gidx)) {
+                    b.t = t;
+                    best_gidx = gi;
+                    plane_won = true;
+                    plane_n = v3(pb.x, pb.y, pb.z);
+                    plane_od = v3(pd.x, pd.y, pd.z);
+                }
             }
         }
-    }
 
-    // ---- shade the winner (RayTracing.cu:123-157)
-    float distance = kNoHit, shadingValue = 0.0f;
-    V3 normal = v3(0.f, 0.f, 0.f), colour = v3(0.f, 0.f, 0.f);
-    if (plane_won || best.k != 0xffffffffu) {
-        V3 n0, objc;
-        if (plane_won) {
-            n0 = plane_n;
-            objc = plane_col;
-        } else {
-            // Sphere.cu:67: (origin + direction * t1 - spherePos).Normalize_GPU()
-            n0 = normalize_gpu(sub(add(ray.o, mulf(ray.d, best.t)), v3(wgeom.x, wgeom.y, wgeom.z)));
-            objc = v3(wcol.x, wcol.y, wcol.z);
+        // ---- shade the winner (RayTracing.cu:123-157)
+        float distance = kNoHit, shadingValue = 0.0f;
+        V3 normal = v3(0.f, 0.f, 0.f), colour = v3(0.f, 0.f, 0.f);
+        if (ABL(32u)) {
+            distance = b.t; normal = ray.d; colour = ray.d; shadingValue = ray.d.x;
+        } else if (plane_won || b.k != 0xffffffffu) {
+            V3 n0, od;
+            if (plane_won) {
+                n0 = plane_n;
+                od = plane_od;
+            } else {
+                // Sphere.cu:67: (origin + direction * t1 - spherePos).Normalize_GPU()
+                n0 = normalize_gpu(sub(add(ray.o, mulf(ray.d, b.t)), v3(wgeom.x, wgeom.y, wgeom.z)));
+                od = v3(wod.x, wod.y, wod.z);
+            }
+            distance = b.t;
+            normal = normalize_gpu(n0);                                         // RayTracing.cu:129
+            shadingValue = normal.x * 1.0f + normal.y * 0.0f + normal.z * 0.0f; // Dot(normal, (1,0,0)), :133
+            if (MODE != RTX_K_RGB_NORMALS && MODE != RTX_K_SDL) {
+                colour = ABL(16u) ? mulf(od, 255.0f) : shade(ray, distance, normal, od);
+            }
         }
-        distance = best.t;
-        normal = normalize_gpu(n0);                                     // RayTracing.cu:129
-        shadingValue = normal.x * 1.0f + normal.y * 0.0f + normal.z * 0.0f; // Dot(normal, (1,0,0)), :133
-        if (MODE != RTX_K_RGB_NORMALS) {
-            colour = shade(ray, distance, normal, objc);
-        }
-    }
 
-    if (MODE != RTX_K_SDL) {
-        encode_and_store<MODE>(a, cam, ray, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
+        if (MODE != RTX_K_SDL && !ABL(64u)) {
+            encode_and_store<MODE>(a, cam, s_digits, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
+        }
     }
 }
 
@@ -345,27 +432,42 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
 
 } // namespace rtx
 
-extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream_v, int* hip_error)
+extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, int nsub, void* stream_v, int* hip_error)
 {
     using namespace rtx;
     hipStream_t stream = (hipStream_t)stream_v;
     const uint32_t lw = a->tile_log2w;
     const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
+    const uint32_t nx = 1u << a->sub_log2nx, ny = (uint32_t)nsub >> a->sub_log2nx;
+    const uint32_t mw = tw * nx, mh = th * ny;
+    *hip_error = 0;
+    if (nx * ny != (uint32_t)nsub || mw > (uint32_t)kMaxMacro || mh > (uint32_t)kMaxMacro) {
+        return nullptr;
+    }
     const uint32_t rows = a->row_end - a->row0;
-    dim3 grid((a->W + tw - 1u) / tw, (rows + th - 1u) / th, 1), block(kThreads, 1, 1);
+    dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
-#define RTX_LAUNCH(M, C)                                                           \
+#define RTX_LAUNCH(M, C, N)                                                        \
     do {                                                                           \
-        hipLaunchKernelGGL((rtx_trace<M, C>), grid, block, 0, stream, *a);         \
-        name = "rtx_trace<" #M "," #C ">";                                         \
+        hipLaunchKernelGGL((rtx_trace<M, C, N>), grid, block, 0, stream, *a);      \
+        name = "rtx_trace<" #M "," #C "," #N ">";                                  \
     } while (0)
-#define RTX_LAUNCH_MODE(M)      \
-    do {                        \
-        if (cull) {             \
-            RTX_LAUNCH(M, true);  \
-        } else {                \
-            RTX_LAUNCH(M, false); \
-        }                       \
+#define RTX_LAUNCH_MODE(M)                                  \
+    do {                                                    \
+        if (!cull) {                                        \
+            if (nsub != 1) return nullptr;                  \
+            RTX_LAUNCH(M, false, 1);                        \
+        } else if (nsub == 1) {                             \
+            RTX_LAUNCH(M, true, 1);                         \
+        } else if (nsub == 2) {                             \
+            RTX_LAUNCH(M, true, 2);                         \
+        } else if (nsub == 4) {                             \
+            RTX_LAUNCH(M, true, 4);                         \
+        } else if (nsub == 8) {                             \
+            RTX_LAUNCH(M, true, 8);                         \
+        } else {                                            \
+            return nullptr;                                 \
+        }                                                   \
     } while (0)
     switch (mode) {
     case RTX_K_BIT_ASCII: RTX_LAUNCH_MODE(RTX_K_BIT_ASCII); break;
@@ -374,7 +476,7 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     case RTX_K_RGB_PIXEL: RTX_LAUNCH_MODE(RTX_K_RGB_PIXEL); break;
     case RTX_K_RGB_NORMALS: RTX_LAUNCH_MODE(RTX_K_RGB_NORMALS); break;
     case RTX_K_SDL: RTX_LAUNCH_MODE(RTX_K_SDL); break;
-    default: *hip_error = 0; return nullptr;
+    default: return nullptr;
     }
 #undef RTX_LAUNCH_MODE
 #undef RTX_LAUNCH

@@ -1,0 +1,69 @@
+// math_check.hip -- TEST INFRASTRUCTURE (built by __graft_entry__.build(), loaded only by tests).
+// Exhaustive verification, on the GPU, that the short correctly-rounded reciprocal and square root
+// of rtx_device.hpp return the same bits as the compiler's IEEE expansions (1.0f / x and sqrtf(x))
+// for EVERY fp32 input.  Each kernel walks all 2^32 bit patterns and counts mismatches.
+#include "../../raytracing-in-windows-console_amd/csrc/rtx_device.hpp"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+__device__ __forceinline__ bool same_bits_or_both_nan(float a, float b)
+{
+    return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+}
+
+template <int WHICH>
+__global__ void check_all(unsigned long long* mismatches, uint32_t* first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float x = __uint_as_float((uint32_t)i);
+        float got, want;
+        if (WHICH == 0) {
+            got = rtx::rcp_cr(x);
+            want = 1.0f / x;
+        } else if (WHICH == 1) {
+            got = rtx::sqrt_cr(x);
+            want = sqrtf(x);
+        } else {
+            // the composition the path uses: 1.0f / sqrt(x)
+            got = rtx::rcp_cr(rtx::sqrt_cr(x));
+            want = 1.0f / sqrtf(x);
+        }
+        if (!same_bits_or_both_nan(got, want)) {
+            bad++;
+            atomicMin(first_bad, (uint32_t)i);
+        }
+    }
+    if (bad) {
+        atomicAdd(mismatches, bad);
+    }
+}
+
+} // namespace
+
+// which: 0 = rcp_cr vs 1.0f/x, 1 = sqrt_cr vs sqrtf, 2 = rcp_cr(sqrt_cr(x)).  Returns the number of
+// mismatching inputs (0 = bit-identical on all 2^32), or -1 on a HIP error.
+extern "C" __attribute__((visibility("default"))) long long rtx_check_math_exhaustive(int which, unsigned* first_bad_bits)
+{
+    unsigned long long* d_bad = nullptr;
+    uint32_t* d_first = nullptr;
+    if (hipMalloc(&d_bad, 8) != hipSuccess || hipMalloc(&d_first, 4) != hipSuccess) return -1;
+    unsigned long long zero = 0;
+    uint32_t maxu = 0xffffffffu;
+    hipMemcpy(d_bad, &zero, 8, hipMemcpyHostToDevice);
+    hipMemcpy(d_first, &maxu, 4, hipMemcpyHostToDevice);
+    if (which == 0) hipLaunchKernelGGL(check_all<0>, dim3(4096), dim3(256), 0, 0, d_bad, d_first);
+    else if (which == 1) hipLaunchKernelGGL(check_all<1>, dim3(4096), dim3(256), 0, 0, d_bad, d_first);
+    else hipLaunchKernelGGL(check_all<2>, dim3(4096), dim3(256), 0, 0, d_bad, d_first);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    unsigned long long bad = 0;
+    hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    hipMemcpy(first_bad_bits, d_first, 4, hipMemcpyDeviceToHost);
+    hipFree(d_bad);
+    hipFree(d_first);
+    return (long long)bad;
+}

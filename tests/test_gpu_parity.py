@@ -39,9 +39,10 @@ def assert_same(got, want, mode, W, what):
 KERNELS = ["brute", "binned"]
 
 
-def set_kernel(R, ctx, kernel, tile=0):
+def set_kernel(R, ctx, kernel, tile=0, subtiles=0):
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, tile)
+    ctx.set_option(R.OPT_SUBTILES, subtiles)
 
 
 # ---------------------------------------------------------------- reference default scene
@@ -132,11 +133,12 @@ def test_c3_brute_equals_binned(R, ctx):
 
 # ---------------------------------------------------------------- properties and edge cases
 
+@pytest.mark.parametrize("subtiles", [1, 2, 4, 8])
 @pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
-def test_every_tile_shape_gives_the_same_frame(R, ctx, tile):
+def test_every_tile_shape_gives_the_same_frame(R, ctx, tile, subtiles):
     p, sph, pl = R.config_inputs("C2")
     ctx.set_scene(sph, pl)
-    set_kernel(R, ctx, "binned", tile)
+    set_kernel(R, ctx, "binned", tile, subtiles)
     got = ctx.render_to_host(p, R.RGB_ASCII)
     assert O.fnv1a64(got) == U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
 
@@ -153,6 +155,7 @@ def test_row_slabs_assemble_to_the_full_frame(R, ctx):
     for parts in (1, 2, 4, 8, 7):
         # full-frame destination
         dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the context renders on its own non-blocking stream
         bounds = [H * i // parts for i in range(parts + 1)]
         for i in range(parts):
             ctx.render_rows(p, R.RGB_ASCII, bounds[i], bounds[i + 1] - bounds[i], d_out=dst.data_ptr(), out_row_base=0)
@@ -163,6 +166,7 @@ def test_row_slabs_assemble_to_the_full_frame(R, ctx):
         for i in range(parts):
             rows = bounds[i + 1] - bounds[i]
             slab = torch.zeros(20 * W * rows, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # the context renders on its own non-blocking stream
             ctx.render_rows(p, R.RGB_ASCII, bounds[i], rows, d_out=slab.data_ptr(), out_row_base=bounds[i])
             ctx.synchronize()
             pieces.append(slab.cpu().numpy())
@@ -191,6 +195,7 @@ def test_sdl_mode_writes_nothing(R, ctx):
     ctx.set_reference_default_scene()
     p = R.camera_params(64, 32)
     dst = torch.full((20 * 64 * 32,), 7, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the context renders on its own non-blocking stream
     ctx.render_rows(p, R.SDL, 0, 32, d_out=dst.data_ptr())
     ctx.synchronize()
     assert bool((dst == 7).all())
@@ -274,9 +279,10 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
     want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
     for kernel in KERNELS:
         for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
-            set_kernel(R, ctx, kernel, tile)
-            got = ctx.render_to_host(p, R.RGB_ASCII)
-            assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d" % (seed, kernel, tile))
+            for sub in ((0,) if kernel == "brute" else (1, 4, 8)):
+                set_kernel(R, ctx, kernel, tile, sub)
+                got = ctx.render_to_host(p, R.RGB_ASCII)
+                assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d" % (seed, kernel, tile, sub))
 
 
 def test_per_pixel_values_within_tolerance(R, ctx):

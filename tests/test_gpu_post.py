@@ -30,6 +30,7 @@ def test_minimize_matches_oracle_default_scene(R, ctx, res, mode):
     p = R.camera_params(w, h)
     ctx.render(p, mode)
     dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the context renders on its own non-blocking stream
     n = ctx.minimize(mode, w, h, d_out=dst.data_ptr())
     frame = ctx.read_frame(20 * w * h)
     want = O.minimize(mode, frame, w, h)
@@ -47,6 +48,7 @@ def test_minimize_c2_full_size_against_golden(R, ctx):
     for mode in (R.RGB_ASCII, R.BIT_ASCII):
         ctx.render(p, mode)
         dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the context renders on its own non-blocking stream
         n = ctx.minimize(mode, W, H, d_out=dst.data_ptr())
         g = gold["C2_%s" % R.MODE_NAMES[mode]]
         assert n == g["minimized_bytes"]
@@ -62,10 +64,12 @@ def test_minimize_sdl_and_empty_rows(R, ctx):
     ctx.render(p, R.RGB_ASCII)
     ctx.render(p, R.SDL)
     dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the context renders on its own non-blocking stream
     n = ctx.minimize(R.SDL, w, h, d_out=dst.data_ptr())
     assert bytes(dst.cpu().numpy()[:n]) == b"\n" * h
     # a frame with only some rows rendered (others NUL): colour persistence skips the empty rows
     frame = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()  # the context renders on its own non-blocking stream
     ctx.render_rows(p, R.RGB_PIXEL, 2, 2, d_out=frame.data_ptr(), out_row_base=0)
     ctx.render_rows(p, R.RGB_PIXEL, 6, 1, d_out=frame.data_ptr(), out_row_base=0)
     ctx.synchronize()
@@ -81,6 +85,7 @@ def test_minimize_width_one_and_two(R, ctx):
         p = R.camera_params(w, h)
         ctx.render(p, R.BIT_ASCII)
         dst = torch.zeros(20 * w * h + 4, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()  # the context renders on its own non-blocking stream
         n = ctx.minimize(R.BIT_ASCII, w, h, d_out=dst.data_ptr())
         want = O.minimize(O.BIT_ASCII, ctx.read_frame(20 * w * h), w, h)
         assert np.array_equal(dst.cpu().numpy()[:n], want)

@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="check the assembled frame against the golden hash")
+    ap.add_argument("--what", default="trace", choices=["trace", "update"],
+                    help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
+                         "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
     args = ap.parse_args()
 
     import numpy as np
@@ -104,8 +107,12 @@ def main():
 
     kernel_ms = None
     if not distributed:
-        def step():
-            ctx.render(params, mode)
+        if args.what == "update":
+            def step():
+                ctx.update(params, mode)
+        else:
+            def step():
+                ctx.render(params, mode)
 
         for _ in range(Wm):
             step()
@@ -242,6 +249,9 @@ def main():
                        "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs + RCCL p2p gather to rank 0" % n_gpus},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if args.what == "update":
+            out["metric"] = "Mrays/s through the whole Update (trace + minimise + D2H of the minimised stream); not the graded metric"
+            out["roofline"] = None
         if verified is not None:
             out["verified_against_golden"] = verified
         if cpu:

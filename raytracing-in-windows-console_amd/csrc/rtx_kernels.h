@@ -26,7 +26,8 @@ struct KArgs {
     uint32_t out_row_base;    // the row stored at out[0]
     uint32_t ns, np;          // spheres, planes
     uint32_t tile_log2w;      // a sub-tile is 2^lw x 2^(8-lw) pixels (one pixel per thread)
-    uint32_t sub_log2nx;      // a workgroup's macro tile is 2^lnx sub-tiles wide, NSUB >> lnx high
+    uint32_t nsub;            // sub-tiles per workgroup (power of two)
+    uint32_t sub_log2nx;      // a workgroup's macro tile is 2^lnx sub-tiles wide, nsub >> lnx high
     // Scene, SoA in HBM (creation order within each kind; .w of the colour arrays carries the
     // creation index across kinds as uint bits; the raw colours stay in host-visible arrays of the
     // context for rtx_scene_get_object):
@@ -45,6 +46,6 @@ struct KArgs {
 extern "C" {
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
-const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, int nsub, void* stream, int* hip_error);
+const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 }

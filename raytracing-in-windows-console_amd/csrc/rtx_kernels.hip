@@ -29,7 +29,7 @@ namespace rtx {
 
 constexpr int kThreads = 256;
 constexpr int kListCapBrute = 1024;  // candidate records per flush (brute: every sphere is a candidate)
-constexpr int kListCapCull = 512;    // culling kernels: lists are short; 10 KiB keeps 8 workgroups per CU
+constexpr int kListCapCull = 704;    // culling kernels: room for one more 512-sphere step while <= 192 are listed; 8 workgroups per CU
 constexpr float kNoHit = 99999999.f; // RayTracing.h:21
 
 // RayTracing.h:97-115 (68 glyphs).
@@ -98,6 +98,13 @@ __device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t co
     }
     const float alen2 = dot(axis, axis);
     f.n[4] = (alen2 > 1.0e-30f && alen2 < 1.0e30f) ? mulf(axis, __builtin_amdgcn_rsqf(alen2)) : v3(0.0f, 0.0f, 0.0f);
+    // every lane computed the same values: keep them in scalar registers
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        f.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].x)));
+        f.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].y)));
+        f.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].z)));
+    }
     return f;
 }
 
@@ -236,25 +243,102 @@ __device__ __forceinline__ Ray ray_from_tables(const Camera& c, float4 A, float4
     return r;
 }
 
-constexpr int kMaxMacro = 128; // macro tile is at most 128 x 128 pixels
+constexpr int kMaxMacro = 128;    // macro tile is at most 128 x 128 pixels
+constexpr int kChunk = 2 * kThreads; // spheres staged per barrier: two per thread
+constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes take the direct path
 
-template <int MODE, bool CULL, int NSUB>
+// One staging step: spheres [base, base + 512), two per thread.  g0/g1 are this thread's geometry
+// records (already loaded: the caller prefetches the next step's before calling).  Hoists the
+// ray-independent terms, culls, and appends survivors to the LDS list in index order (wave ballots,
+// per-wave counts through LDS, one barrier).  Returns the new list length (uniform).
+template <bool CULL>
+__device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
+                                                float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8], uint32_t parity, uint32_t total, bool drop_all)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    bool keep[2];
+    float4 rec[2];
+    const float4 g[2] = {g0, g1};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t k = base + (uint32_t)h * kThreads + tid;
+        keep[h] = false;
+        rec[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < ns) {
+            // objectToCam = origin - spherePos; c = Dot(otc,otc) - r*r   (Sphere.cu:34-37)
+            const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
+            const float oo = ox * ox + oy * oy + oz * oz;
+            const float cc = oo - (g[h].w * g[h].w);
+            rec[h] = make_float4(ox, oy, oz, cc);
+            keep[h] = !drop_all;
+            if (CULL) {
+                // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
+                if (cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w)) {
+                    keep[h] = false;
+                }
+            }
+        }
+    }
+    const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+    if (lane == 0) {
+        s_wcnt[parity][wave] = (uint32_t)__popcll(m0);
+        s_wcnt[parity][4 + wave] = (uint32_t)__popcll(m1);
+    }
+    // LDS-only barrier: the caller's prefetched global loads stay in flight across it.  It also orders
+    // the previous scan's list reads before the writes below.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    uint32_t before = 0, sum = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 8u; w++) {
+        const uint32_t c = s_wcnt[parity][w];
+        sum += c;
+        if (w < wave) before += c; // first halves of earlier waves (wave <= 3)
+    }
+    // index order: [first-half survivors of waves 0..3][second-half survivors of waves 0..3]
+    uint32_t first_total = 0, before1 = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4u; w++) {
+        first_total += s_wcnt[parity][w];
+        if (w < wave) before1 += s_wcnt[parity][4 + w];
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (keep[0]) {
+        const uint32_t pos = total + before + (uint32_t)__popcll(m0 & below);
+        s_rec[pos] = rec[0];
+        s_idx[pos] = base + tid;
+    }
+    if (keep[1]) {
+        const uint32_t pos = total + first_total + before1 + (uint32_t)__popcll(m1 & below);
+        s_rec[pos] = rec[1];
+        s_idx[pos] = base + kThreads + tid;
+    }
+    return __builtin_amdgcn_readfirstlane(total + sum);
+}
+
+__device__ __forceinline__ float4 load_geom(const float4* __restrict__ p, uint32_t k, uint32_t ns)
+{
+    return k < ns ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int MODE, bool CULL>
 __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
 {
     constexpr int kListCap = CULL ? kListCapCull : kListCapBrute;
     __shared__ float4 s_rec[kListCap];
     __shared__ uint32_t s_idx[kListCap];
-    __shared__ float4 s_col[kMaxMacro];  // per column: (m0, m4, m8) * vx
-    __shared__ float4 s_row[kMaxMacro];  // per row:    (m1, m5, m9) * vy
-    __shared__ uint32_t s_digits[256];   // three decimal digits of 0..255, NUL padded
-    __shared__ uint32_t s_wcnt[2][4];    // survivors per wave of the current chunk, double-buffered
+    __shared__ float4 s_col[kMaxMacro];          // per column: (m0, m4, m8) * vx
+    __shared__ float4 s_row[kMaxMacro];          // per row:    (m1, m5, m9) * vy
+    __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
+    __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
+    __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
     const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
-    const uint32_t lnx = a.sub_log2nx;              // sub-tiles are laid out nx wide, NSUB/nx high
-    const uint32_t nx = 1u << lnx, ny = (uint32_t)NSUB >> lnx;
-    const uint32_t mw = tw * nx, mh = th * ny;      // macro tile, pixels
+    const uint32_t lnx = a.sub_log2nx;           // sub-tiles are laid out nx wide, nsub/nx high
+    const uint32_t nsub = a.nsub;
+    const uint32_t nx = 1u << lnx, ny = nsub >> lnx;
+    const uint32_t mw = tw * nx, mh = th * ny;   // macro tile, pixels
     const uint32_t mcol0 = blockIdx.x * mw;
     const uint32_t mrow0 = a.row0 + blockIdx.y * mh;
     const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
@@ -267,6 +351,10 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     cam.ox = a.ox; cam.oy = a.oy; cam.oz = a.oz;
     cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
     cam.fW = a.fW; cam.fH = a.fH;
+
+    // first staging step's loads go out before anything else
+    const uint32_t ns = ABL(1u) ? 0u : a.ns;
+    float4 g0 = load_geom(a.sph_geom, tid, ns), g1 = load_geom(a.sph_geom, kThreads + tid, ns);
 
     // ---- per-workgroup tables (visible after the first barrier below)
     s_digits[tid] = digits3(tid);
@@ -282,76 +370,44 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         const float vy = ((cam.fH - (float)(r * 2u)) / cam.fH) * cam.e2;
         s_row[tid - mw] = make_float4(cam.m[1] * vy, cam.m[5] * vy, cam.m[9] * vy, 0.0f);
     }
+    const uint32_t np = ABL(8u) ? 0u : a.np;
+    const uint32_t np_tab = np < (uint32_t)kPlaneTable ? np : (uint32_t)kPlaneTable;
+    if (tid < np_tab) {
+        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
+        const float4 pa = a.pl_a[tid], pb = a.pl_b[tid];
+        const V3 p = v3(pa.x, pa.y, pa.z), n = v3(pb.x, pb.y, pb.z);
+        const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
+        const float hw = pa.w * 0.5f, hh = pb.w * 0.5f;
+        s_plane[3 * tid + 0] = make_float4(n.x, n.y, n.z, num);
+        s_plane[3 * tid + 1] = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
+        s_plane[3 * tid + 2] = a.pl_od[tid];
+    }
 
     TileFrustum fr;
     if (CULL) {
         fr = tile_frustum(cam, mcol0, mrow0, mw, mh);
     }
 
-    Best best[NSUB];
-#pragma unroll
-    for (int j = 0; j < NSUB; j++) {
-        best[j].t = kNoHit;
-        best[j].k = 0xffffffffu;
-    }
-
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
+    // ---- stage the whole scene once
     uint32_t total = 0; // candidates in the list; identical in every thread
     uint32_t parity = 0;
-    for (uint32_t base = 0; base < (ABL(1u) ? 0u : a.ns); base += kThreads, parity ^= 1u) {
-        // ---- stage one chunk: hoist, cull, append in index order
-        const uint32_t k = base + tid;
-        bool keep = false;
-        float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < a.ns) {
-            const float4 g = a.sph_geom[k]; // cx cy cz r
-            // objectToCam = origin - spherePos; c = Dot(otc,otc) - r*r   (Sphere.cu:34-37)
-            const float ox = cam.ox - g.x, oy = cam.oy - g.y, oz = cam.oz - g.z;
-            const float oo = ox * ox + oy * oy + oz * oz;
-            const float cc = oo - (g.w * g.w);
-            rec = make_float4(ox, oy, oz, cc);
-            keep = true;
-            if (CULL) {
-                // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
-                if (cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g.w)) {
-                    keep = false;
-                }
-            }
-            if (ABL(2u)) keep = false;
+    bool overflow = !CULL && ns > (uint32_t)kListCap; // brute: every sphere is a candidate
+    for (uint32_t base = 0; base < ns && !overflow; base += kChunk, parity ^= 1u) {
+        const float4 c0 = g0, c1 = g1;
+        g0 = load_geom(a.sph_geom, base + kChunk + tid, ns); // prefetch the next step
+        g1 = load_geom(a.sph_geom, base + kChunk + kThreads + tid, ns);
+        if (total > (uint32_t)(kListCap - kChunk)) {
+            overflow = true; // the list cannot take another step: fall back to one scene walk per sub-tile
+            break;
         }
-        const unsigned long long m = __ballot(keep);
-        if (lane == 0) {
-            s_wcnt[parity][wave] = (uint32_t)__popcll(m);
-        }
-        __syncthreads(); // also orders the previous flush's list reads before the writes below
-        const uint32_t c0 = s_wcnt[parity][0], c1 = s_wcnt[parity][1], c2 = s_wcnt[parity][2], c3 = s_wcnt[parity][3];
-        if (keep) {
-            const uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
-            const uint32_t pos = total + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            s_rec[pos] = rec;
-            s_idx[pos] = k;
-        }
-        total = __builtin_amdgcn_readfirstlane(total + c0 + c1 + c2 + c3);
-        const bool last = base + kThreads >= a.ns;
-        if (total > (uint32_t)(kListCap - kThreads) && !last) {
-            // ---- the list is full before the scene ends: fold it into every sub-tile's best hit
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < NSUB; j++) {
-                const uint32_t jx = (uint32_t)j & (nx - 1u), jy = (uint32_t)j >> lnx;
-                Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
-                scan_candidates(ray, s_rec, s_idx, total, best[j]);
-            }
-            total = 0;
-        }
+        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u));
     }
-    __syncthreads(); // list complete (and tables visible when the scene has no spheres)
+    __syncthreads(); // list complete, tables visible
 
     // ---- one pass per sub-tile
-#pragma unroll
-    for (int j = 0; j < NSUB; j++) {
-        const uint32_t jx = (uint32_t)j & (nx - 1u), jy = (uint32_t)j >> lnx;
+#pragma unroll 1
+    for (uint32_t j = 0; j < nsub; j++) {
+        const uint32_t jx = j & (nx - 1u), jy = j >> lnx;
         const uint32_t scol0 = mcol0 + jx * tw, srow0 = mrow0 + jy * th;
         if (scol0 >= a.W || srow0 >= a.row_end) {
             continue; // sub-tile entirely outside the frame (uniform)
@@ -361,8 +417,29 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         const bool newline_col = col + 1u == a.W;
         // lanes outside the frame trace a clamped pixel (the tables clamp) so every lane runs the same loops
         Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
-        Best b = best[j];
-        if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
+        Best b;
+        b.t = kNoHit;
+        b.k = 0xffffffffu;
+        if (!overflow) {
+            if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
+        } else {
+            // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
+            // the list into the best hit whenever it fills.
+            __syncthreads();
+            uint32_t tot = 0, par = 0;
+            float4 h0 = load_geom(a.sph_geom, tid, ns), h1 = load_geom(a.sph_geom, kThreads + tid, ns);
+            for (uint32_t base = 0; base < ns; base += kChunk, par ^= 1u) {
+                const float4 c0 = h0, c1 = h1;
+                h0 = load_geom(a.sph_geom, base + kChunk + tid, ns);
+                h1 = load_geom(a.sph_geom, base + kChunk + kThreads + tid, ns);
+                tot = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, s_rec, s_idx, s_wcnt, par, tot, false);
+                if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= ns) {
+                    __syncthreads();
+                    scan_candidates(ray, s_rec, s_idx, tot, b);
+                    tot = 0;
+                }
+            }
+        }
 
         // ---- winner among spheres: creation index for the tie-break against planes
         uint32_t best_gidx = 0xffffffffu;
@@ -373,10 +450,35 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
             best_gidx = __float_as_uint(wod.w);
         }
 
-        // ---- planes (few; wave-uniform index -> scalar loads)
+        // ---- planes: hoisted form from LDS (wave-uniform index: broadcast reads), Plane.cu:38-72
         bool plane_won = false;
         V3 plane_n = v3(0.f, 0.f, 0.f), plane_od = v3(0.f, 0.f, 0.f);
-        for (uint32_t q = 0; q < (ABL(8u) ? 0u : a.np); q++) {
+        for (uint32_t q = 0; q < np_tab; q++) {
+            const float4 pn = s_plane[3 * q + 0];
+            const float dn = ray.d.x * pn.x + ray.d.y * pn.y + ray.d.z * pn.z;
+            if (dn > 0.0f || fabsf(dn - 0.0f) < 1.1920928955078125e-7f) {
+                continue;
+            }
+            const float t1 = pn.w / dn;
+            if (t1 <= 0.0f) {
+                continue;
+            }
+            const float4 bd = s_plane[3 * q + 1];
+            const float hx = ray.o.x + ray.d.x * t1, hz = ray.o.z + ray.d.z * t1;
+            if ((hx <= bd.x || hx >= bd.y) || (hz <= bd.z || hz >= bd.w)) {
+                continue;
+            }
+            const float4 pd = s_plane[3 * q + 2];
+            const uint32_t gi = __float_as_uint(pd.w);
+            if (t1 < b.t || (t1 == b.t && gi < best_gidx)) {
+                b.t = t1;
+                best_gidx = gi;
+                plane_won = true;
+                plane_n = v3(pn.x, pn.y, pn.z);
+                plane_od = v3(pd.x, pd.y, pd.z);
+            }
+        }
+        for (uint32_t q = np_tab; q < np; q++) { // beyond the LDS table: the direct form
             const float4 pa = a.pl_a[q]; // px py pz width
             const float4 pb = a.pl_b[q]; // nx ny nz height
             float t;
@@ -432,42 +534,33 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
 
 } // namespace rtx
 
-extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, int nsub, void* stream_v, int* hip_error)
+extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream_v, int* hip_error)
 {
     using namespace rtx;
     hipStream_t stream = (hipStream_t)stream_v;
     const uint32_t lw = a->tile_log2w;
     const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
-    const uint32_t nx = 1u << a->sub_log2nx, ny = (uint32_t)nsub >> a->sub_log2nx;
+    const uint32_t nx = 1u << a->sub_log2nx, ny = a->nsub >> a->sub_log2nx;
     const uint32_t mw = tw * nx, mh = th * ny;
     *hip_error = 0;
-    if (nx * ny != (uint32_t)nsub || mw > (uint32_t)kMaxMacro || mh > (uint32_t)kMaxMacro) {
+    if (a->nsub == 0 || nx * ny != a->nsub || mw > (uint32_t)kMaxMacro || mh > (uint32_t)kMaxMacro || mw + mh > (uint32_t)kThreads) {
         return nullptr;
     }
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
-#define RTX_LAUNCH(M, C, N)                                                        \
+#define RTX_LAUNCH(M, C)                                                           \
     do {                                                                           \
-        hipLaunchKernelGGL((rtx_trace<M, C, N>), grid, block, 0, stream, *a);      \
-        name = "rtx_trace<" #M "," #C "," #N ">";                                  \
+        hipLaunchKernelGGL((rtx_trace<M, C>), grid, block, 0, stream, *a);         \
+        name = "rtx_trace<" #M "," #C ">";                                         \
     } while (0)
-#define RTX_LAUNCH_MODE(M)                                  \
-    do {                                                    \
-        if (!cull) {                                        \
-            if (nsub != 1) return nullptr;                  \
-            RTX_LAUNCH(M, false, 1);                        \
-        } else if (nsub == 1) {                             \
-            RTX_LAUNCH(M, true, 1);                         \
-        } else if (nsub == 2) {                             \
-            RTX_LAUNCH(M, true, 2);                         \
-        } else if (nsub == 4) {                             \
-            RTX_LAUNCH(M, true, 4);                         \
-        } else if (nsub == 8) {                             \
-            RTX_LAUNCH(M, true, 8);                         \
-        } else {                                            \
-            return nullptr;                                 \
-        }                                                   \
+#define RTX_LAUNCH_MODE(M)        \
+    do {                          \
+        if (cull) {               \
+            RTX_LAUNCH(M, true);  \
+        } else {                  \
+            RTX_LAUNCH(M, false); \
+        }                         \
     } while (0)
     switch (mode) {
     case RTX_K_BIT_ASCII: RTX_LAUNCH_MODE(RTX_K_BIT_ASCII); break;

@@ -133,7 +133,7 @@ def test_c3_brute_equals_binned(R, ctx):
 
 # ---------------------------------------------------------------- properties and edge cases
 
-@pytest.mark.parametrize("subtiles", [1, 2, 4, 8])
+@pytest.mark.parametrize("subtiles", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("tile", [2, 3, 4, 5, 6])
 def test_every_tile_shape_gives_the_same_frame(R, ctx, tile, subtiles):
     p, sph, pl = R.config_inputs("C2")
@@ -306,3 +306,50 @@ def test_per_pixel_values_within_tolerance(R, ctx):
         want = np.trunc(px["color"][..., ch][vis]).astype(np.int32)
         assert np.array_equal(val, want)
         assert np.all(np.abs(val - px["color"][..., ch][vis]) <= 1.0 + TOL_REL * 255)
+
+
+def test_candidate_list_overflow_path(R, ctx):
+    """More candidates per macro tile than the LDS list holds (hundreds of spheres stacked on the same
+    pixels): the kernel falls back to one scene walk per sub-tile and must still pick, per pixel, the
+    nearest sphere with the lowest creation index."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    # all spheres straddle the view axis at increasing depth, so every tile keeps most of them
+    z = np.sort(rng.uniform(20, 200, n))[::-1]  # far ones created first
+    centres = np.stack([rng.normal(0, 1.0, n), rng.normal(0, 0.3, n), z], axis=1)
+    radii = rng.uniform(2.0, 6.0, n)
+    cols = np.floor(rng.uniform(1, 256, (n, 3)))
+    sph = np.concatenate([centres, radii[:, None], cols], axis=1).astype(np.float32)
+    sph[100] = sph[99]  # an exact duplicate: the tie goes to the earlier one
+    pl = np.zeros((0, 11), dtype=np.float32)
+    ctx.set_scene(sph, pl)
+    sc = O.Scene.from_arrays(sph, pl)
+    p = R.camera_params(256, 96)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
+    for kernel, tile, sub in (("brute", 0, 0), ("binned", 0, 1), ("binned", 0, 4), ("binned", 3, 8), ("binned", 5, 16)):
+        set_kernel(R, ctx, kernel, tile, sub)
+        got = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(got, want, O.RGB_ASCII, 256, "overflow %s tile %d sub %d" % (kernel, tile, sub))
+
+
+def test_many_planes_beyond_the_lds_table(R, ctx):
+    """More planes than the kernel hoists into LDS (16): the rest take the direct Plane::Trace form."""
+    rng = np.random.default_rng(11)
+    ctx.scene_clear()
+    sc = O.Scene()
+    for i in range(40):
+        pos = (float(rng.uniform(-40, 40)), float(rng.uniform(-25, -2)), float(rng.uniform(20, 150)))
+        nrm = (float(rng.normal(0, 0.2)), 1.0, float(rng.normal(0, 0.2)))
+        col = [float(v) for v in np.floor(rng.uniform(1, 256, 3))]
+        w, h = float(rng.uniform(5, 60)), float(rng.uniform(5, 60))
+        ctx.add_plane(pos, nrm, col, w, h)
+        sc.add_plane(pos, nrm, col, w, h)
+        if i % 5 == 0:
+            ctx.add_sphere(3.0, (pos[0], pos[1] + 6, pos[2]), col)
+            sc.add_sphere(3.0, (pos[0], pos[1] + 6, pos[2]), col)
+    p = R.camera_params(320, 120)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=4)
+    for kernel in KERNELS:
+        set_kernel(R, ctx, kernel)
+        got = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(got, want, O.RGB_ASCII, 320, "40 planes %s" % kernel)

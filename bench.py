@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "brute", "binned"])
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--subtiles", type=int, default=0)
+    ap.add_argument("--two-level", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="check the assembled frame against the golden hash")
@@ -99,6 +100,7 @@ def main():
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[args.kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, args.tile)
     ctx.set_option(R.OPT_SUBTILES, args.subtiles)
+    ctx.set_option(R.OPT_TWO_LEVEL, args.two_level)
 
     K, Wm = args.steps, args.warmup
     bounds = sharding.row_bounds(H, world)

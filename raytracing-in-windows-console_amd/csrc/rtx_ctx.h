@@ -43,6 +43,10 @@ struct rtx_ctx {
     int64_t opt_kernel = RTX_KERNEL_AUTO;
     int64_t opt_tile_log2w = 0;
     int64_t opt_subtiles = 0;
+    int64_t opt_two_level = -1;     // -1 auto, 0 off, 1 on
+    uint32_t* d_cell_list = nullptr; // two-level culling scratch
+    uint32_t* d_cell_count = nullptr;
+    size_t cell_list_words = 0, cell_count_words = 0;
 
     std::string error;
     const char* last_kernel = "";

@@ -103,16 +103,14 @@ __device__ __forceinline__ float pow32(float x)
     return (float)d;
 }
 
-// (uint8_t)f as the CUDA hardware conversion does it: truncate; negatives and NaN give 0.
+// (uint8_t)f as the CUDA hardware conversion does it: truncate; negatives and NaN give 0, values past
+// the u32 range saturate (low byte 255).  v_cvt_u32_f32 has exactly these semantics; it is spelled in
+// asm because a C++ float->unsigned cast of an out-of-range value is undefined.
 __device__ __forceinline__ uint32_t u8_sat(float f)
 {
-    if (!(f > 0.0f)) {
-        return 0u;
-    }
-    if (f >= 4294967296.0f) {
-        return 255u;
-    }
-    return ((uint32_t)f) & 255u;
+    uint32_t u;
+    asm("v_cvt_u32_f32 %0, %1" : "=v"(u) : "v"(f));
+    return u & 255u;
 }
 
 struct Ray {

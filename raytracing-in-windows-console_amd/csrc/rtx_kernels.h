@@ -37,6 +37,14 @@ struct KArgs {
     const float4* pl_b;       // nx ny nz height
     const float4* pl_od;      // R/255 G/255 B/255 gidx
     const uint8_t* grey;      // 256-byte grey lookup of the xterm-256 mapper
+    // Two-level culling (large scenes): per coarse cell, ascending sphere indices (stride ns) and their count.
+    // cell_list == nullptr: every workgroup stages the whole scene.
+    const uint32_t* cell_list;
+    const uint32_t* cell_count;
+    uint32_t* cell_list_out;  // rtx_bin_cells writes these two
+    uint32_t* cell_count_out;
+    uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
+    uint32_t cells_x;
     uint8_t* out;             // records of row out_row_base start here
 #ifdef RTX_ABLATE
     uint32_t ablate;          // experiment builds only (make ablate): bit mask of stages to skip
@@ -47,5 +55,6 @@ extern "C" {
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
+int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 }

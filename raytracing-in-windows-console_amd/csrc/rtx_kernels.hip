@@ -98,13 +98,6 @@ __device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t co
     }
     const float alen2 = dot(axis, axis);
     f.n[4] = (alen2 > 1.0e-30f && alen2 < 1.0e30f) ? mulf(axis, __builtin_amdgcn_rsqf(alen2)) : v3(0.0f, 0.0f, 0.0f);
-    // every lane computed the same values: keep them in scalar registers
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        f.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].x)));
-        f.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].y)));
-        f.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(f.n[k].z)));
-    }
     return f;
 }
 
@@ -247,13 +240,14 @@ constexpr int kMaxMacro = 128;    // macro tile is at most 128 x 128 pixels
 constexpr int kChunk = 2 * kThreads; // spheres staged per barrier: two per thread
 constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes take the direct path
 
-// One staging step: spheres [base, base + 512), two per thread.  g0/g1 are this thread's geometry
-// records (already loaded: the caller prefetches the next step's before calling).  Hoists the
+// One staging step: items [base, base + 512) of `ns` items, two per thread.  g0/g1 (sphere indices k0/k1)
+// are this thread's geometry records, already loaded: the caller prefetches the next step's first.  Hoists the
 // ray-independent terms, culls, and appends survivors to the LDS list in index order (wave ballots,
 // per-wave counts through LDS, one barrier).  Returns the new list length (uniform).
 template <bool CULL>
 __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
-                                                float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8], uint32_t parity, uint32_t total, bool drop_all)
+                                                uint32_t k0, uint32_t k1, float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8],
+                                                uint32_t parity, uint32_t total, bool drop_all)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep[2];
@@ -261,22 +255,16 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
     const float4 g[2] = {g0, g1};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const uint32_t k = base + (uint32_t)h * kThreads + tid;
-        keep[h] = false;
-        rec[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < ns) {
-            // objectToCam = origin - spherePos; c = Dot(otc,otc) - r*r   (Sphere.cu:34-37)
-            const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
-            const float oo = ox * ox + oy * oy + oz * oz;
-            const float cc = oo - (g[h].w * g[h].w);
-            rec[h] = make_float4(ox, oy, oz, cc);
-            keep[h] = !drop_all;
-            if (CULL) {
-                // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
-                if (cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w)) {
-                    keep[h] = false;
-                }
-            }
+        const uint32_t k = base + (uint32_t)h * kThreads + tid; // item number; valid while below ns (the item count)
+        // objectToCam = origin - spherePos; c = Dot(otc,otc) - r*r   (Sphere.cu:34-37)
+        const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
+        const float oo = ox * ox + oy * oy + oz * oz;
+        const float cc = oo - (g[h].w * g[h].w);
+        rec[h] = make_float4(ox, oy, oz, cc);
+        keep[h] = (k < ns) && !drop_all;
+        if (CULL) {
+            // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
+            keep[h] = keep[h] && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
         }
     }
     const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
@@ -305,19 +293,34 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
     if (keep[0]) {
         const uint32_t pos = total + before + (uint32_t)__popcll(m0 & below);
         s_rec[pos] = rec[0];
-        s_idx[pos] = base + tid;
+        s_idx[pos] = k0;
     }
     if (keep[1]) {
         const uint32_t pos = total + first_total + before1 + (uint32_t)__popcll(m1 & below);
         s_rec[pos] = rec[1];
-        s_idx[pos] = base + kThreads + tid;
+        s_idx[pos] = k1;
     }
     return __builtin_amdgcn_readfirstlane(total + sum);
 }
 
-__device__ __forceinline__ float4 load_geom(const float4* __restrict__ p, uint32_t k, uint32_t ns)
+// The spheres a workgroup stages: all of them (list == nullptr), or the index list its coarse cell
+// received from rtx_bin_cells (two-level culling for large scenes).
+struct Items {
+    const float4* geom;
+    const uint32_t* list; // sphere indices in ascending order, or nullptr
+    uint32_t count;       // number of items
+};
+
+// Item i: its sphere index and geometry record.  Past the end any valid record is returned (ignored).
+__device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_t& k)
 {
-    return k < ns ? p[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (it.count == 0u) {
+        k = 0u;
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const uint32_t ii = i < it.count ? i : it.count - 1u;
+    k = it.list ? it.list[ii] : ii;
+    return it.geom[k];
 }
 
 template <int MODE, bool CULL>
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
     __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
+    __shared__ float s_frustum[16];              // the macro tile's five plane normals
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
@@ -352,9 +356,21 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
     cam.fW = a.fW; cam.fH = a.fH;
 
+    // what this workgroup stages: the whole scene, or its coarse cell's list (two-level culling)
+    Items items;
+    items.geom = a.sph_geom;
+    items.list = nullptr;
+    items.count = a.ns;
+    if (CULL && a.cell_list != nullptr) {
+        const uint32_t cell = (blockIdx.y >> a.cell_log2gy) * a.cells_x + (blockIdx.x >> a.cell_log2gx);
+        items.list = a.cell_list + (size_t)cell * a.ns;
+        items.count = a.cell_count[cell];
+    }
+    if (ABL(1u)) items.count = 0u;
+    const uint32_t ns = items.count;
     // first staging step's loads go out before anything else
-    const uint32_t ns = ABL(1u) ? 0u : a.ns;
-    float4 g0 = load_geom(a.sph_geom, tid, ns), g1 = load_geom(a.sph_geom, kThreads + tid, ns);
+    uint32_t k0, k1;
+    float4 g0 = load_item(items, tid, k0), g1 = load_item(items, kThreads + tid, k1);
 
     // ---- per-workgroup tables (visible after the first barrier below)
     s_digits[tid] = digits3(tid);
@@ -383,9 +399,28 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         s_plane[3 * tid + 2] = a.pl_od[tid];
     }
 
+    // The culling pyramid is the same for the whole workgroup: wave 0 computes it, the others pick it
+    // up from LDS into scalar registers.
     TileFrustum fr;
     if (CULL) {
-        fr = tile_frustum(cam, mcol0, mrow0, mw, mh);
+        if (tid < 64u) {
+            const TileFrustum f0 = tile_frustum(cam, mcol0, mrow0, mw, mh);
+            if (tid == 0u) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    s_frustum[3 * k + 0] = f0.n[k].x;
+                    s_frustum[3 * k + 1] = f0.n[k].y;
+                    s_frustum[3 * k + 2] = f0.n[k].z;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            fr.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
+            fr.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 1])));
+            fr.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
+        }
     }
 
     // ---- stage the whole scene once
@@ -394,13 +429,14 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     bool overflow = !CULL && ns > (uint32_t)kListCap; // brute: every sphere is a candidate
     for (uint32_t base = 0; base < ns && !overflow; base += kChunk, parity ^= 1u) {
         const float4 c0 = g0, c1 = g1;
-        g0 = load_geom(a.sph_geom, base + kChunk + tid, ns); // prefetch the next step
-        g1 = load_geom(a.sph_geom, base + kChunk + kThreads + tid, ns);
+        const uint32_t j0 = k0, j1 = k1;
+        g0 = load_item(items, base + kChunk + tid, k0); // prefetch the next step
+        g1 = load_item(items, base + kChunk + kThreads + tid, k1);
         if (total > (uint32_t)(kListCap - kChunk)) {
             overflow = true; // the list cannot take another step: fall back to one scene walk per sub-tile
             break;
         }
-        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u));
+        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u));
     }
     __syncthreads(); // list complete, tables visible
 
@@ -427,12 +463,14 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
             // the list into the best hit whenever it fills.
             __syncthreads();
             uint32_t tot = 0, par = 0;
-            float4 h0 = load_geom(a.sph_geom, tid, ns), h1 = load_geom(a.sph_geom, kThreads + tid, ns);
+            uint32_t i0, i1;
+            float4 h0 = load_item(items, tid, i0), h1 = load_item(items, kThreads + tid, i1);
             for (uint32_t base = 0; base < ns; base += kChunk, par ^= 1u) {
                 const float4 c0 = h0, c1 = h1;
-                h0 = load_geom(a.sph_geom, base + kChunk + tid, ns);
-                h1 = load_geom(a.sph_geom, base + kChunk + kThreads + tid, ns);
-                tot = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, s_rec, s_idx, s_wcnt, par, tot, false);
+                const uint32_t j0 = i0, j1 = i1;
+                h0 = load_item(items, base + kChunk + tid, i0);
+                h1 = load_item(items, base + kChunk + kThreads + tid, i1);
+                tot = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= ns) {
                     __syncthreads();
                     scan_candidates(ray, s_rec, s_idx, tot, b);
@@ -443,16 +481,12 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
 
         // ---- winner among spheres: creation index for the tie-break against planes
         uint32_t best_gidx = 0xffffffffu;
-        float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wod = make_float4(0.f, 0.f, 0.f, 0.f);
         if (b.k != 0xffffffffu) {
-            wgeom = a.sph_geom[b.k];
-            wod = a.sph_od[b.k];
-            best_gidx = __float_as_uint(wod.w);
+            best_gidx = __float_as_uint(a.sph_od[b.k].w);
         }
 
         // ---- planes: hoisted form from LDS (wave-uniform index: broadcast reads), Plane.cu:38-72
-        bool plane_won = false;
-        V3 plane_n = v3(0.f, 0.f, 0.f), plane_od = v3(0.f, 0.f, 0.f);
+        uint32_t plane_q = 0xffffffffu; // winning plane, if a plane beats the best sphere
         for (uint32_t q = 0; q < np_tab; q++) {
             const float4 pn = s_plane[3 * q + 0];
             const float dn = ray.d.x * pn.x + ray.d.y * pn.y + ray.d.z * pn.z;
@@ -468,14 +502,11 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
             if ((hx <= bd.x || hx >= bd.y) || (hz <= bd.z || hz >= bd.w)) {
                 continue;
             }
-            const float4 pd = s_plane[3 * q + 2];
-            const uint32_t gi = __float_as_uint(pd.w);
+            const uint32_t gi = __float_as_uint(s_plane[3 * q + 2].w);
             if (t1 < b.t || (t1 == b.t && gi < best_gidx)) {
                 b.t = t1;
                 best_gidx = gi;
-                plane_won = true;
-                plane_n = v3(pn.x, pn.y, pn.z);
-                plane_od = v3(pd.x, pd.y, pd.z);
+                plane_q = q;
             }
         }
         for (uint32_t q = np_tab; q < np; q++) { // beyond the LDS table: the direct form
@@ -483,29 +514,28 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
             const float4 pb = a.pl_b[q]; // nx ny nz height
             float t;
             if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
-                const float4 pd = a.pl_od[q]; // R/255 G/255 B/255 gidx
-                const uint32_t gi = __float_as_uint(pd.w);
+                const uint32_t gi = __float_as_uint(a.pl_od[q].w);
                 if (t < b.t || (t == b.t && gi < best_gidx)) {
                     b.t = t;
                     best_gidx = gi;
-                    plane_won = true;
-                    plane_n = v3(pb.x, pb.y, pb.z);
-                    plane_od = v3(pd.x, pd.y, pd.z);
+                    plane_q = q;
                 }
             }
         }
 
-        // ---- shade the winner (RayTracing.cu:123-157)
+        // ---- shade the winner (RayTracing.cu:123-157).  Values of a missed pixel are never encoded.
         float distance = kNoHit, shadingValue = 0.0f;
-        V3 normal = v3(0.f, 0.f, 0.f), colour = v3(0.f, 0.f, 0.f);
+        V3 normal = ray.d, colour = ray.d;
         if (ABL(32u)) {
-            distance = b.t; normal = ray.d; colour = ray.d; shadingValue = ray.d.x;
-        } else if (plane_won || b.k != 0xffffffffu) {
+            distance = b.t; shadingValue = ray.d.x;
+        } else if (plane_q != 0xffffffffu || b.k != 0xffffffffu) {
             V3 n0, od;
-            if (plane_won) {
-                n0 = plane_n;
-                od = plane_od;
+            if (plane_q != 0xffffffffu) {
+                const float4 pb = a.pl_b[plane_q], pd = a.pl_od[plane_q];
+                n0 = v3(pb.x, pb.y, pb.z);
+                od = v3(pd.x, pd.y, pd.z);
             } else {
+                const float4 wgeom = a.sph_geom[b.k], wod = a.sph_od[b.k];
                 // Sphere.cu:67: (origin + direction * t1 - spherePos).Normalize_GPU()
                 n0 = normalize_gpu(sub(add(ray.o, mulf(ray.d, b.t)), v3(wgeom.x, wgeom.y, wgeom.z)));
                 od = v3(wod.x, wod.y, wod.z);
@@ -521,6 +551,98 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         if (MODE != RTX_K_SDL && !ABL(64u)) {
             encode_and_store<MODE>(a, cam, s_digits, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
         }
+    }
+}
+
+// Level 1 of the two-level culling used for large scenes: one workgroup per coarse cell (a block of
+// 2^gx x 2^gy macro tiles) walks the whole sphere array and writes, in ascending order, the indices of
+// the spheres whose inflated bound can touch the cell's pyramid.  rtx_trace<.., true> then stages only
+// its cell's list.  Same conservative test as the per-tile one, on a larger rectangle.
+__global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
+{
+    __shared__ uint32_t s_wcnt[2][8];
+    __shared__ float s_frustum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tw = 1u << a.tile_log2w, th = (uint32_t)kThreads >> a.tile_log2w;
+    const uint32_t nx = 1u << a.sub_log2nx, ny = a.nsub >> a.sub_log2nx;
+    const uint32_t cw = (tw * nx) << a.cell_log2gx, ch = (th * ny) << a.cell_log2gy; // cell, pixels
+    const uint32_t cell = blockIdx.y * a.cells_x + blockIdx.x;
+
+    Camera cam;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        cam.m[i] = a.m[i];
+    }
+    cam.ox = a.ox; cam.oy = a.oy; cam.oz = a.oz;
+    cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
+    cam.fW = a.fW; cam.fH = a.fH;
+
+    TileFrustum fr;
+    if (tid < 64u) {
+        const TileFrustum f0 = tile_frustum(cam, blockIdx.x * cw, a.row0 + blockIdx.y * ch, cw, ch);
+        if (tid == 0u) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                s_frustum[3 * k + 0] = f0.n[k].x;
+                s_frustum[3 * k + 1] = f0.n[k].y;
+                s_frustum[3 * k + 2] = f0.n[k].z;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        fr.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
+        fr.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 1])));
+        fr.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
+    }
+
+    uint32_t* out = a.cell_list_out + (size_t)cell * a.ns;
+    const uint32_t ns = a.ns;
+    uint32_t total = 0, parity = 0;
+    float4 g0 = a.sph_geom[tid < ns ? tid : ns - 1u], g1 = a.sph_geom[kThreads + tid < ns ? kThreads + tid : ns - 1u];
+    for (uint32_t base = 0; base < ns; base += kChunk, parity ^= 1u) {
+        const float4 g[2] = {g0, g1};
+        const uint32_t n0 = base + kChunk + tid, n1 = n0 + kThreads;
+        g0 = a.sph_geom[n0 < ns ? n0 : ns - 1u];
+        g1 = a.sph_geom[n1 < ns ? n1 : ns - 1u];
+        bool keep[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t k = base + (uint32_t)h * kThreads + tid;
+            const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
+            const float oo = ox * ox + oy * oy + oz * oz;
+            const float cc = oo - (g[h].w * g[h].w);
+            keep[h] = (k < ns) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
+        }
+        const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+        if (lane == 0) {
+            s_wcnt[parity][wave] = (uint32_t)__popcll(m0);
+            s_wcnt[parity][4 + wave] = (uint32_t)__popcll(m1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        uint32_t before = 0, before1 = 0, first_total = 0, sum = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; w++) {
+            const uint32_t c0 = s_wcnt[parity][w], c1 = s_wcnt[parity][4 + w];
+            first_total += c0;
+            sum += c0 + c1;
+            if (w < wave) {
+                before += c0;
+                before1 += c1;
+            }
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (keep[0]) {
+            out[total + before + (uint32_t)__popcll(m0 & below)] = base + tid;
+        }
+        if (keep[1]) {
+            out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = base + kThreads + tid;
+        }
+        total += sum;
+    }
+    if (tid == 0) {
+        a.cell_count_out[cell] = total;
     }
 }
 
@@ -575,6 +697,12 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
 #undef RTX_LAUNCH
     *hip_error = (int)hipGetLastError();
     return name;
+}
+
+extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, void* stream_v)
+{
+    hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(cells_x, cells_y, 1), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
+    return (int)hipGetLastError();
 }
 
 extern "C" int rtx_k_launch_zero(void* p, size_t bytes, void* stream_v)

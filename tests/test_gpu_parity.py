@@ -39,10 +39,11 @@ def assert_same(got, want, mode, W, what):
 KERNELS = ["brute", "binned"]
 
 
-def set_kernel(R, ctx, kernel, tile=0, subtiles=0):
+def set_kernel(R, ctx, kernel, tile=0, subtiles=0, two_level=-1):
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, tile)
     ctx.set_option(R.OPT_SUBTILES, subtiles)
+    ctx.set_option(R.OPT_TWO_LEVEL, two_level)
 
 
 # ---------------------------------------------------------------- reference default scene
@@ -126,9 +127,39 @@ def test_c3_brute_equals_binned(R, ctx):
     ctx.set_scene(sph, pl)
     set_kernel(R, ctx, "brute")
     a = ctx.render_to_host(p, R.RGB_ASCII)
-    set_kernel(R, ctx, "binned")
-    b = ctx.render_to_host(p, R.RGB_ASCII)
-    assert_same(b, a, R.RGB_ASCII, int(p.x), "C3 binned vs brute")
+    for two in (0, 1):
+        set_kernel(R, ctx, "binned", two_level=two)
+        b = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(b, a, R.RGB_ASCII, int(p.x), "C3 binned (two-level %d) vs brute" % two)
+
+
+@pytest.mark.parametrize("two", [0, 1])
+@pytest.mark.parametrize("mode", [O.BIT_ASCII, O.RGB_ASCII, O.RGB_NORMALS])
+def test_two_level_culling_on_c2(R, ctx, mode, two):
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    set_kernel(R, ctx, "binned", two_level=two)
+    got = ctx.render_to_host(p, mode)
+    if mode == O.RGB_NORMALS:
+        set_kernel(R, ctx, "brute")
+        assert_same(got, ctx.render_to_host(p, mode), mode, int(p.x), "C2 normals two-level %d vs brute" % two)
+    else:
+        assert O.fnv1a64(got) == U.load_golden()["C2_%s" % O.MODE_NAMES[mode]]["frame_fnv1a64"]
+
+
+def test_two_level_row_slabs(R, ctx):
+    """Two-level culling inside row-slab launches (cells are laid out from the slab's first row)."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    set_kernel(R, ctx, "binned", two_level=1)
+    dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for (r0, r1) in ((0, 135), (135, 541), (541, 1080)):
+        ctx.render_rows(p, R.RGB_ASCII, r0, r1 - r0, d_out=dst.data_ptr(), out_row_base=0)
+    ctx.synchronize()
+    assert O.fnv1a64(dst.cpu().numpy()) == U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
 
 
 # ---------------------------------------------------------------- properties and edge cases
@@ -280,9 +311,10 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
     for kernel in KERNELS:
         for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
             for sub in ((0,) if kernel == "brute" else (1, 4, 8)):
-                set_kernel(R, ctx, kernel, tile, sub)
-                got = ctx.render_to_host(p, R.RGB_ASCII)
-                assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d" % (seed, kernel, tile, sub))
+                for two in ((0,) if kernel == "brute" else (0, 1)):
+                    set_kernel(R, ctx, kernel, tile, sub, two)
+                    got = ctx.render_to_host(p, R.RGB_ASCII)
+                    assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d two-level %d" % (seed, kernel, tile, sub, two))
 
 
 def test_per_pixel_values_within_tolerance(R, ctx):
@@ -326,10 +358,11 @@ def test_candidate_list_overflow_path(R, ctx):
     sc = O.Scene.from_arrays(sph, pl)
     p = R.camera_params(256, 96)
     want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
-    for kernel, tile, sub in (("brute", 0, 0), ("binned", 0, 1), ("binned", 0, 4), ("binned", 3, 8), ("binned", 5, 16)):
-        set_kernel(R, ctx, kernel, tile, sub)
+    for kernel, tile, sub, two in (("brute", 0, 0, 0), ("binned", 0, 1, 0), ("binned", 0, 4, 0), ("binned", 3, 8, 1), ("binned", 5, 16, 0),
+                                   ("binned", 0, 4, 1)):
+        set_kernel(R, ctx, kernel, tile, sub, two)
         got = ctx.render_to_host(p, R.RGB_ASCII)
-        assert_same(got, want, O.RGB_ASCII, 256, "overflow %s tile %d sub %d" % (kernel, tile, sub))
+        assert_same(got, want, O.RGB_ASCII, 256, "overflow %s tile %d sub %d two-level %d" % (kernel, tile, sub, two))
 
 
 def test_many_planes_beyond_the_lds_table(R, ctx):

@@ -205,18 +205,24 @@ def main():
         my_rows = rows
         bytes_alg = algorithmic_bytes(W, H, S, ns, npl, my_rows)
         achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters of the committed profile of this same kernel
+        # (profiles/traffic.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none.
         traffic = None
+        traffic_detail = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and my_rows == H:
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get("%s_%s_%s" % (args.config, args.mode, ctx.last_kernel), None)
-            except (OSError, ValueError):
+                    traffic_detail = json.load(f).get("%s_%s_%s" % (args.config, args.mode, ctx.last_kernel), None)
+                if traffic_detail:
+                    traffic = round(traffic_detail["total_bytes"])
+            except (OSError, ValueError, KeyError):
                 traffic = None
         flops = algorithmic_flops(W, H, ns, npl, hit_frac) * (my_rows / float(H))
         roofline = {
             "bound": "hbm", "kernel": ctx.last_kernel, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "traffic_unit": "bytes per launch (compare with bytes_per_launch)", "traffic_source": (traffic_detail or {}).get("source"),
             "bytes_per_launch": bytes_alg, "kernel_ms": round(kernel_ms, 5),
             # second view: the brute-force form of this path is fp32-VALU bound, not HBM bound
             "valu": {"flops_per_launch": flops, "achieved": round(flops / (kernel_ms * 1e-3) / 1e12, 3),

@@ -161,6 +161,12 @@ int rtx_update_objects(rtx_ctx* ctx, double dt);
 int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics,
                void* host_out, size_t* out_bytes);
 
+/* ---- pinned host memory for the buffers Update copies into (m_minimizedResultArray / m_hostResultArray,
+ * RayTracingManager.cu:62-66, which the reference allocates pageable): device-to-host copies into it run at
+ * PCIe rate instead of through a staging bounce.  Optional: any host pointer is accepted by rtx_update. */
+void* rtx_host_alloc(rtx_ctx* ctx, size_t bytes);
+void rtx_host_free(rtx_ctx* ctx, void* p);
+
 /* ---- measurement helpers (bench.py): HIP events on the context's stream. */
 int rtx_timer_start(rtx_ctx* ctx);
 int rtx_timer_stop(rtx_ctx* ctx, float* elapsed_ms); /* records, synchronises, returns start->stop */

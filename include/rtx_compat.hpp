@@ -324,9 +324,15 @@ public:
         // the constructor sizes its buffers from PrintMachine::GetMaxSize() (RayTracingManager.cu:58-66)
         if (PrintMachine::GetMaxSize() == 0) throw std::runtime_error("PrintMachine::Start must precede RayTracingManager()");
         m_ctx = rtx_compat::Device::get(PrintMachine::GetWidth(), PrintMachine::GetHeight());
-        m_minimizedResultArray.reset(new char[PrintMachine::GetMaxSize()]);
+        // pinned, so that the copy of the minimised stream runs at PCIe rate (the reference's is pageable)
+        m_minimizedResultArray = static_cast<char*>(rtx_host_alloc(m_ctx, PrintMachine::GetMaxSize()));
+        if (!m_minimizedResultArray) throw std::runtime_error(std::string("rtx_host_alloc: ") + rtx_last_error(m_ctx));
     }
-    ~RayTracingManager() = default; // the shared context is released by PrintMachine::CleanUp()
+    ~RayTracingManager()
+    {
+        // the shared context itself is released by PrintMachine::CleanUp()
+        if (rtx_compat::Device::slot() == m_ctx) rtx_host_free(m_ctx, m_minimizedResultArray);
+    }
 
     // Synchronous, like the reference: on return the minimised frame is in PrintMachine's back buffer.
     void Update(const RayTracingCPUToGPUData& params, const DeviceObjectArray<Object3D*>& deviceObjects, double dt)
@@ -337,13 +343,13 @@ public:
         const rtx_params p = rtx_compat::to_rtx_params(params);
         size_t newSize = 0;
         rtx_compat::check(m_ctx, rtx_update(m_ctx, &p, (int)currentRenderingMode, dt, /*run_physics=*/1,
-                                            m_minimizedResultArray.get(), &newSize), "rtx_update");
-        PrintMachine::SetDataInBackBuffer(m_minimizedResultArray.get(), newSize);
+                                            m_minimizedResultArray, &newSize), "rtx_update");
+        PrintMachine::SetDataInBackBuffer(m_minimizedResultArray, newSize);
     }
     void SetRenderingMode(const RenderingMode newRenderMode) { currentRenderingMode = newRenderMode; }
 
 private:
     rtx_ctx* m_ctx = nullptr;
-    std::unique_ptr<char[]> m_minimizedResultArray;
+    char* m_minimizedResultArray = nullptr;
     RenderingMode currentRenderingMode = BIT_ASCII; // RayTracingManager.h:53
 };

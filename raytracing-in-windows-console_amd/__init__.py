@@ -67,6 +67,8 @@ _SIGNATURES = [
     ("rtx_minimized_device_ptr", _P, [_P]),
     ("rtx_update_objects", C.c_int, [_P, C.c_double]),
     ("rtx_update", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_size_t)]),
+    ("rtx_host_alloc", _P, [_P, C.c_size_t]),
+    ("rtx_host_free", None, [_P, _P]),
     ("rtx_timer_start", C.c_int, [_P]),
     ("rtx_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("rtx_last_kernel_name", C.c_char_p, [_P]),
@@ -156,8 +158,23 @@ class Context:
 
     def close(self):
         if self._h:
+            if getattr(self, "_pinned", None):
+                lib().rtx_host_free(self._h, self._pinned[0])
+                self._pinned = None
             lib().rtx_destroy(self._h)
             self._h = _P()
+
+    def _pinned_buffer(self, nbytes):
+        """A pinned host buffer of at least nbytes (what m_minimizedResultArray is in the facade)."""
+        cur = getattr(self, "_pinned", None)
+        if cur is None or cur[1] < nbytes:
+            if cur is not None:
+                lib().rtx_host_free(self._h, cur[0])
+            p = lib().rtx_host_alloc(self._h, nbytes)
+            if not p:
+                raise RtxError(ERR_OUT_OF_MEMORY, "rtx_host_alloc")
+            self._pinned = (p, nbytes, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+        return self._pinned
 
     def __del__(self):
         try:
@@ -276,10 +293,10 @@ class Context:
 
     def update(self, params, mode, dt=0.0, run_physics=False):
         """RayTracingManager::Update: returns the minimised byte stream handed to PrintMachine."""
-        out = np.empty(20 * int(params.x) * int(params.y), dtype=np.uint8)
+        ptr, _, arr = self._pinned_buffer(20 * int(params.x) * int(params.y))
         n = C.c_size_t()
-        self._check(lib().rtx_update(self._h, C.byref(params), mode, dt, 1 if run_physics else 0, out.ctypes.data, C.byref(n)))
-        return out[:n.value]
+        self._check(lib().rtx_update(self._h, C.byref(params), mode, dt, 1 if run_physics else 0, ptr, C.byref(n)))
+        return arr[:n.value]  # a view of the pinned buffer: valid until the next update()
 
     # -- timing on the context's stream
     def timer_start(self):

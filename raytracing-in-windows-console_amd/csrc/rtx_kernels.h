@@ -37,7 +37,7 @@ struct KArgs {
     const float4* pl_b;       // nx ny nz height
     const float4* pl_od;      // R/255 G/255 B/255 gidx
     const uint8_t* grey;      // 256-byte grey lookup of the xterm-256 mapper
-    // Two-level culling (large scenes): per coarse cell, ascending sphere indices (stride ns) and their count.
+    // Two-level culling (large scenes): per coarse cell, sphere indices (stride ns, any order) and their count.
     // cell_list == nullptr: every workgroup stages the whole scene.
     const uint32_t* cell_list;
     const uint32_t* cell_count;
@@ -55,6 +55,6 @@ extern "C" {
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
-int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, void* stream);
+int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 }

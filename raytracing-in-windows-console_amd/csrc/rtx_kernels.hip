@@ -40,13 +40,13 @@ __constant__ const char kRamp[68] = {
     'k', 'h', 'a', 'o', '#', '%', 'Z', 'O', '8', 'B', '$', '0', 'Q', 'M', '&', 'W', '@'
 };
 
-// Conservative inflation of a sphere for culling.  A ray whose fp32 test reports a hit passes,
-// in exact arithmetic, within R = sqrt(r^2 (1+2u) + 15u |otc|^2) of the centre (u = 2^-24;
-// derivation in DESIGN.md "Culling soundness"), and no further than 3u|otc| behind the apex.
-// kappa = 4e-6 > 4 * 15u; sqrt(a+b) <= sqrt(a) + sqrt(b) gives the linear form used here, and
-// kSlack covers the rounding of the plane evaluation itself.
-constexpr float kKappa = 4.0e-6f;
-constexpr float kSqrtKappaPlusSlack = 2.0e-3f + 1.0e-4f;
+// Conservative inflation of a sphere for culling.  A ray whose fp32 test reports a hit passes, in exact
+// arithmetic, within R of the centre with R^2 = r^2 (1+2u) + 15.2u |otc|^2 (u = 2^-24; derivation in
+// DESIGN.md "Culling soundness"), and no further than 3u|otc| behind the apex.  kappa = 2e-6 is 2.2x
+// that constant; kDelta |otc| covers the apex term and the rounding of the plane evaluation, of the
+// plane normals and of the hardware sqrt used below (together < 1.5e-6 |otc|).
+constexpr float kKappa = 2.0e-6f;
+constexpr float kDelta = 5.0e-6f;
 
 struct TileFrustum {
     V3 n[5]; // inward unit normals of the four side planes, then the tile axis
@@ -105,7 +105,7 @@ __device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t co
 __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float oy, float oz, float oo, float r)
 {
     // margin >= R + 3u|otc| + evaluation slack (see kKappa); hardware sqrt is within 1 ulp
-    const float margin = r * (1.0f + kKappa) + kSqrtKappaPlusSlack * __builtin_amdgcn_sqrtf(oo);
+    const float margin = __builtin_amdgcn_sqrtf(r * r * (1.0f + kKappa) + kKappa * oo) + kDelta * __builtin_amdgcn_sqrtf(oo);
     bool out = false;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -307,7 +307,7 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
 // received from rtx_bin_cells (two-level culling for large scenes).
 struct Items {
     const float4* geom;
-    const uint32_t* list; // sphere indices in ascending order, or nullptr
+    const uint32_t* list; // sphere indices (any order), or nullptr
     uint32_t count;       // number of items
 };
 
@@ -554,14 +554,34 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     }
 }
 
-// Level 1 of the two-level culling used for large scenes: one workgroup per coarse cell (a block of
-// 2^gx x 2^gy macro tiles) walks the whole sphere array and writes, in ascending order, the indices of
-// the spheres whose inflated bound can touch the cell's pyramid.  rtx_trace<.., true> then stages only
-// its cell's list.  Same conservative test as the per-tile one, on a larger rectangle.
+// Level 1 of the two-level culling used for large scenes.  Workgroup (cell, split) walks its share of
+// the sphere array and collects, for its coarse cell (a block of 2^gx x 2^gy macro tiles), the indices
+// of the spheres whose inflated bound can touch the cell's pyramid: same conservative test as the
+// per-tile one, on a larger rectangle.  Survivors are gathered in LDS and appended to the cell's list
+// with one atomic reservation per flush (cell_count must be zero at launch).  The order of the list
+// does not matter: the closest hit is the minimum of (t, creation index).
+constexpr int kBinCap = 2048; // indices gathered in LDS between flushes
+
+__device__ __forceinline__ void bin_flush(uint32_t* s_out, uint32_t n, uint32_t* out, uint32_t* count, uint32_t* s_base)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *s_base = atomicAdd(count, n);
+    }
+    __syncthreads();
+    const uint32_t base = *s_base;
+    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
+        out[base + i] = s_out[i];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
 {
+    __shared__ uint32_t s_out[kBinCap];
     __shared__ uint32_t s_wcnt[2][8];
     __shared__ float s_frustum[16];
+    __shared__ uint32_t s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tw = 1u << a.tile_log2w, th = (uint32_t)kThreads >> a.tile_log2w;
     const uint32_t nx = 1u << a.sub_log2nx, ny = a.nsub >> a.sub_log2nx;
@@ -598,14 +618,25 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
     }
 
     uint32_t* out = a.cell_list_out + (size_t)cell * a.ns;
-    const uint32_t ns = a.ns;
+    uint32_t* count = a.cell_count_out + cell;
+    // this workgroup's share of the spheres: [lo, hi), a multiple of the step size except at the end
+    const uint32_t ns = a.ns, splits = gridDim.z;
+    const uint32_t steps = (ns + kChunk - 1) / kChunk;
+    const uint32_t lo = (uint32_t)(((uint64_t)steps * blockIdx.z) / splits) * kChunk;
+    const uint32_t hi_raw = (uint32_t)(((uint64_t)steps * (blockIdx.z + 1)) / splits) * kChunk;
+    const uint32_t hi = hi_raw < ns ? hi_raw : ns;
+
     uint32_t total = 0, parity = 0;
-    float4 g0 = a.sph_geom[tid < ns ? tid : ns - 1u], g1 = a.sph_geom[kThreads + tid < ns ? kThreads + tid : ns - 1u];
-    for (uint32_t base = 0; base < ns; base += kChunk, parity ^= 1u) {
+    float4 g0 = a.sph_geom[lo + tid < ns ? lo + tid : ns - 1u], g1 = a.sph_geom[lo + kThreads + tid < ns ? lo + kThreads + tid : ns - 1u];
+    for (uint32_t base = lo; base < hi; base += kChunk, parity ^= 1u) {
         const float4 g[2] = {g0, g1};
         const uint32_t n0 = base + kChunk + tid, n1 = n0 + kThreads;
         g0 = a.sph_geom[n0 < ns ? n0 : ns - 1u];
         g1 = a.sph_geom[n1 < ns ? n1 : ns - 1u];
+        if (total > (uint32_t)(kBinCap - kChunk)) {
+            bin_flush(s_out, total, out, count, &s_base);
+            total = 0;
+        }
         bool keep[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -613,7 +644,7 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
             const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
             const float oo = ox * ox + oy * oy + oz * oz;
             const float cc = oo - (g[h].w * g[h].w);
-            keep[h] = (k < ns) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
+            keep[h] = (k < hi) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
         }
         const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
         if (lane == 0) {
@@ -634,15 +665,15 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         if (keep[0]) {
-            out[total + before + (uint32_t)__popcll(m0 & below)] = base + tid;
+            s_out[total + before + (uint32_t)__popcll(m0 & below)] = base + tid;
         }
         if (keep[1]) {
-            out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = base + kThreads + tid;
+            s_out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = base + kThreads + tid;
         }
-        total += sum;
+        total = __builtin_amdgcn_readfirstlane(total + sum);
     }
-    if (tid == 0) {
-        a.cell_count_out[cell] = total;
+    if (total) {
+        bin_flush(s_out, total, out, count, &s_base);
     }
 }
 
@@ -699,9 +730,9 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     return name;
 }
 
-extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, void* stream_v)
+extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream_v)
 {
-    hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(cells_x, cells_y, 1), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
+    hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(cells_x, cells_y, splits), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
     return (int)hipGetLastError();
 }
 

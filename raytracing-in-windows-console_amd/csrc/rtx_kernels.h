@@ -48,6 +48,7 @@ struct KArgs {
     uint8_t* out;             // records of row out_row_base start here
 #ifdef RTX_ABLATE
     uint32_t ablate;          // experiment builds only (make ablate): bit mask of stages to skip
+    unsigned long long* stamps; // experiment builds only: 16 timestamps per workgroup (s_memtime), or nullptr
 #endif
 };
 

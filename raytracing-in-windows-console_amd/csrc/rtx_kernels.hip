@@ -23,9 +23,25 @@ namespace rtx {
 // the stage is to be skipped.  In the product build it is the constant false.
 #ifdef RTX_ABLATE
 #define ABL(bit) ((a.ablate & (bit)) != 0u)
+// wave 0 of each workgroup stamps the shader clock into its slot of a.stamps (diagnostic build only)
+#define STAMP(i)                                                                                            \
+    do {                                                                                                    \
+        if (a.stamps && threadIdx.x == 0) {                                                                 \
+            unsigned long long t__;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
+            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t__;                         \
+        }                                                                                                   \
+    } while (0)
 #else
 #define ABL(bit) false
+#define STAMP(i) do { } while (0)
 #endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding
+// global loads (s_waitcnt vmcnt(0)), which would expose the latency of every prefetch in flight; in
+// these kernels threads exchange data through LDS alone (global memory is read-only input or
+// write-only output), so waiting for LDS operations is sufficient.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 constexpr int kThreads = 256;
 constexpr int kListCapBrute = 1024;  // candidate records per flush (brute: every sphere is a candidate)
@@ -122,7 +138,7 @@ struct Best {
 };
 
 template <int MODE>
-__device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const uint32_t* s_digits, bool in_frame, bool is_newline_col,
+__device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const uint32_t* s_digits, const uint8_t* s_ramp, bool in_frame, bool is_newline_col,
                                                  uint32_t row, uint32_t col, float distance, V3 normal, V3 colour, float shadingValue)
 {
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
@@ -156,7 +172,7 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
             }
             const uint32_t dr = s_digits[r], dg = s_digits[g], db = s_digits[b];
             const uint32_t kind = (MODE == RTX_K_RGB_ASCII) ? '3' : '4';
-            const uint32_t glyph = (MODE == RTX_K_RGB_ASCII) ? (uint32_t)(uint8_t)kRamp[ramp_index(shadingValue)] : (uint32_t)' ';
+            const uint32_t glyph = (MODE == RTX_K_RGB_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
             w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
             w1 = (uint32_t)';' | ((uint32_t)'2' << 8) | ((uint32_t)';' << 16) | ((dr & 255u) << 24);
             w2 = (dr >> 8) | ((uint32_t)';' << 16) | ((dg & 255u) << 24);
@@ -181,7 +197,7 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
             const uint32_t index = ansi256_from_rgb(u8_sat(colour.x), u8_sat(colour.y), u8_sat(colour.z), a.grey);
             const uint32_t d = s_digits[index];
             const uint32_t kind = (MODE == RTX_K_BIT_ASCII) ? '3' : '4';
-            const uint32_t glyph = (MODE == RTX_K_BIT_ASCII) ? (uint32_t)(uint8_t)kRamp[ramp_index(shadingValue)] : (uint32_t)' ';
+            const uint32_t glyph = (MODE == RTX_K_BIT_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
             w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
             w1 = (uint32_t)';' | ((uint32_t)'5' << 8) | ((uint32_t)';' << 16) | ((d & 255u) << 24);
             w2 = (d >> 8) | ((uint32_t)'m' << 16) | (glyph << 24);
@@ -333,6 +349,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     __shared__ float4 s_row[kMaxMacro];          // per row:    (m1, m5, m9) * vy
     __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
     __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
+    __shared__ uint8_t s_ramp[68];               // the glyph ramp (RayTracing.h:97-115)
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
     __shared__ float s_frustum[16];              // the macro tile's five plane normals
 
@@ -356,6 +373,18 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
     cam.fW = a.fW; cam.fH = a.fH;
 
+    STAMP(0);
+#ifdef RTX_ABLATE
+    if (a.stamps && threadIdx.x == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = ((unsigned long long)xcc << 32) | hwid;
+        a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = rt;
+    }
+#endif
     // what this workgroup stages: the whole scene, or its coarse cell's list (two-level culling)
     Items items;
     items.geom = a.sph_geom;
@@ -374,6 +403,9 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
 
     // ---- per-workgroup tables (visible after the first barrier below)
     s_digits[tid] = digits3(tid);
+    if (tid < 68u) {
+        s_ramp[tid] = (uint8_t)kRamp[tid];
+    }
     if (tid < mw) {
         // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
         const uint32_t c = mcol0 + tid < a.W ? mcol0 + tid : a.W - 1u;
@@ -388,15 +420,13 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     }
     const uint32_t np = ABL(8u) ? 0u : a.np;
     const uint32_t np_tab = np < (uint32_t)kPlaneTable ? np : (uint32_t)kPlaneTable;
+    // plane records are requested here and written to the LDS table after the staging loop, so that
+    // their latency overlaps with it
+    float4 pla = make_float4(0.f, 0.f, 0.f, 0.f), plb = pla, pld = pla;
     if (tid < np_tab) {
-        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
-        const float4 pa = a.pl_a[tid], pb = a.pl_b[tid];
-        const V3 p = v3(pa.x, pa.y, pa.z), n = v3(pb.x, pb.y, pb.z);
-        const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
-        const float hw = pa.w * 0.5f, hh = pb.w * 0.5f;
-        s_plane[3 * tid + 0] = make_float4(n.x, n.y, n.z, num);
-        s_plane[3 * tid + 1] = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
-        s_plane[3 * tid + 2] = a.pl_od[tid];
+        pla = a.pl_a[tid];
+        plb = a.pl_b[tid];
+        pld = a.pl_od[tid];
     }
 
     // The culling pyramid is the same for the whole workgroup: wave 0 computes it, the others pick it
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             fr.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
@@ -423,6 +453,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         }
     }
 
+    STAMP(1);
     // ---- stage the whole scene once
     uint32_t total = 0; // candidates in the list; identical in every thread
     uint32_t parity = 0;
@@ -438,7 +469,17 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         }
         total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u));
     }
-    __syncthreads(); // list complete, tables visible
+    if (tid < np_tab) {
+        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
+        const V3 p = v3(pla.x, pla.y, pla.z), n = v3(plb.x, plb.y, plb.z);
+        const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
+        const float hw = pla.w * 0.5f, hh = plb.w * 0.5f;
+        s_plane[3 * tid + 0] = make_float4(n.x, n.y, n.z, num);
+        s_plane[3 * tid + 1] = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
+        s_plane[3 * tid + 2] = pld;
+    }
+    lds_barrier(); // list complete, tables visible
+    STAMP(2);
 
     // ---- one pass per sub-tile
 #pragma unroll 1
@@ -461,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
             // the list into the best hit whenever it fills.
-            __syncthreads();
+            lds_barrier();
             uint32_t tot = 0, par = 0;
             uint32_t i0, i1;
             float4 h0 = load_item(items, tid, i0), h1 = load_item(items, kThreads + tid, i1);
@@ -472,18 +513,22 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
                 h1 = load_item(items, base + kChunk + kThreads + tid, i1);
                 tot = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= ns) {
-                    __syncthreads();
+                    lds_barrier();
                     scan_candidates(ray, s_rec, s_idx, tot, b);
                     tot = 0;
                 }
             }
         }
 
-        // ---- winner among spheres: creation index for the tie-break against planes
+        // ---- winner among spheres: its records are requested now and first used after the plane tests
+        // (the creation index only in an exact tie with a plane)
         uint32_t best_gidx = 0xffffffffu;
+        float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wod = wgeom;
         if (b.k != 0xffffffffu) {
-            best_gidx = __float_as_uint(a.sph_od[b.k].w);
+            wgeom = a.sph_geom[b.k];
+            wod = a.sph_od[b.k];
         }
+        const bool sphere_hit_any = b.k != 0xffffffffu;
 
         // ---- planes: hoisted form from LDS (wave-uniform index: broadcast reads), Plane.cu:38-72
         uint32_t plane_q = 0xffffffffu; // winning plane, if a plane beats the best sphere
@@ -503,7 +548,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
                 continue;
             }
             const uint32_t gi = __float_as_uint(s_plane[3 * q + 2].w);
-            if (t1 < b.t || (t1 == b.t && gi < best_gidx)) {
+            if (t1 < b.t || (t1 == b.t && gi < (plane_q != 0xffffffffu ? best_gidx : (sphere_hit_any ? __float_as_uint(wod.w) : 0xffffffffu)))) {
                 b.t = t1;
                 best_gidx = gi;
                 plane_q = q;
@@ -515,7 +560,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
             float t;
             if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
                 const uint32_t gi = __float_as_uint(a.pl_od[q].w);
-                if (t < b.t || (t == b.t && gi < best_gidx)) {
+                if (t < b.t || (t == b.t && gi < (plane_q != 0xffffffffu ? best_gidx : (sphere_hit_any ? __float_as_uint(wod.w) : 0xffffffffu)))) {
                     b.t = t;
                     best_gidx = gi;
                     plane_q = q;
@@ -535,7 +580,6 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
                 n0 = v3(pb.x, pb.y, pb.z);
                 od = v3(pd.x, pd.y, pd.z);
             } else {
-                const float4 wgeom = a.sph_geom[b.k], wod = a.sph_od[b.k];
                 // Sphere.cu:67: (origin + direction * t1 - spherePos).Normalize_GPU()
                 n0 = normalize_gpu(sub(add(ray.o, mulf(ray.d, b.t)), v3(wgeom.x, wgeom.y, wgeom.z)));
                 od = v3(wod.x, wod.y, wod.z);
@@ -549,8 +593,16 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         }
 
         if (MODE != RTX_K_SDL && !ABL(64u)) {
-            encode_and_store<MODE>(a, cam, s_digits, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
+            encode_and_store<MODE>(a, cam, s_digits, s_ramp, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
         }
+        STAMP(3 + (j < 9u ? j : 9u));
+#ifdef RTX_ABLATE
+        if (a.stamps && threadIdx.x == 0) {
+            unsigned long long rt;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 13] = rt; // end of the latest pass
+        }
+#endif
     }
 }
 

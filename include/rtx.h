@@ -135,6 +135,12 @@ int rtx_render(rtx_ctx* ctx, const rtx_params* params, int mode);
 int rtx_render_rows(rtx_ctx* ctx, const rtx_params* params, int mode, size_t row0, size_t rows,
                     void* d_out, size_t out_row_base, void* stream, unsigned flags);
 
+/* Queues n whole frames with one call (a renderer keeping several frames in flight): frame i is traced with
+ * params[i] into d_outs[i] (each a 20*W*H device buffer of the caller) on streams[i] (hipStream_t).  Frames
+ * queued on different streams with different buffers may execute concurrently; on one stream they run in
+ * order.  Asynchronous; the caller synchronises its streams.  Same effect as n rtx_render_rows calls. */
+int rtx_submit_frames(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode, void* const* d_outs, void* const* streams);
+
 int rtx_synchronize(rtx_ctx* ctx);
 
 /* The context's device result buffer (m_deviceResultArray, RayTracingManager.h:45) and its size. */

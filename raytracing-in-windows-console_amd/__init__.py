@@ -59,6 +59,7 @@ _SIGNATURES = [
     ("rtx_scene_get_object", C.c_int, [_P, C.c_uint, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ("rtx_render", C.c_int, [_P, C.POINTER(Params), C.c_int]),
     ("rtx_render_rows", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, C.c_uint]),
+    ("rtx_submit_frames", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     ("rtx_synchronize", C.c_int, [_P]),
     ("rtx_frame_device_ptr", _P, [_P]),
     ("rtx_frame_capacity", C.c_size_t, [_P]),
@@ -256,6 +257,36 @@ class Context:
 
     def render_rows(self, params, mode, row0, rows, d_out=None, out_row_base=0, stream=None, flags=0):
         self._check(lib().rtx_render_rows(self._h, C.byref(params), mode, row0, rows, d_out, out_row_base, stream, flags))
+
+    def submit_frames(self, params_list, mode, d_outs, streams):
+        """rtx_submit_frames: queue len(params_list) whole frames with one call."""
+        n = len(params_list)
+        pa = (Params * n)(*params_list)
+        oa = (_P * n)(*d_outs)
+        sa = (_P * n)(*streams)
+        self._check(lib().rtx_submit_frames(self._h, n, pa, mode, oa, sa))
+
+    def make_submitter(self, params, mode, d_outs, streams):
+        """Pre-built argument arrays for repeatedly queueing the same batch (bench.py): returns a callable."""
+        n = len(d_outs)
+        pa = (Params * n)(*([params] * n))
+        oa = (_P * n)(*d_outs)
+        sa = (_P * n)(*streams)
+        fn, h = lib().rtx_submit_frames, self._h
+        # pointer triples for every ring position, built once: the per-frame host cost is one foreign call
+        slots = [(C.cast(C.byref(pa, i * C.sizeof(Params)), C.POINTER(Params)),
+                  C.cast(C.byref(oa, i * C.sizeof(_P)), C.POINTER(_P)),
+                  C.cast(C.byref(sa, i * C.sizeof(_P)), C.POINTER(_P))) for i in range(n)]
+        keep = (pa, oa, sa)
+
+        def submit(count=n, first=0):
+            # frames first .. first+count-1 of the ring (count <= n - first)
+            p_, o_, s_ = slots[first]
+            rc = fn(h, count, p_, mode, o_, s_)
+            if rc != OK:
+                self._check(rc)
+        submit._keep = keep
+        return submit
 
     def synchronize(self):
         self._check(lib().rtx_synchronize(self._h))

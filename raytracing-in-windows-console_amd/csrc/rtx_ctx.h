@@ -44,9 +44,15 @@ struct rtx_ctx {
     int64_t opt_tile_log2w = 0;
     int64_t opt_subtiles = 0;
     int64_t opt_two_level = -1;     // -1 auto, 0 off, 1 on
-    uint32_t* d_cell_list = nullptr; // two-level culling scratch
-    uint32_t* d_cell_count = nullptr;
-    size_t cell_list_words = 0, cell_count_words = 0;
+    // two-level culling scratch, one set per stream that renders (launches on one stream are ordered, so a
+    // set is never shared by frames in flight on different streams)
+    struct CellScratch {
+        hipStream_t stream = nullptr;
+        uint32_t* list = nullptr;
+        uint32_t* count = nullptr;
+        size_t list_words = 0, count_words = 0;
+    };
+    std::vector<CellScratch> cell_scratch;
 
     std::string error;
     const char* last_kernel = "";

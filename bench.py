@@ -168,57 +168,20 @@ def main():
     else:
         import torch.distributed as dist
         stream = torch.cuda.current_stream()
-        nbuf = 2
-        if rank == 0:
-            frames = [torch.zeros(frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-        else:
-            slabs = [torch.zeros(S * W * rows, dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-        pending = [None] * nbuf
+        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2)
 
-        def step(i):
-            b = i % nbuf
-            if pending[b] is not None:      # the transfer that last used this buffer
-                sharding.wait_all(pending[b])
-                pending[b] = None
-            if rank == 0:
-                # root traces its own rows straight into the frame and receives every peer's slab at
-                # that peer's byte offset (row-major rows: a slab is one contiguous range)
-                ctx.render_rows(params, mode, row0, rows, d_out=frames[b].data_ptr(), out_row_base=0,
-                                stream=stream.cuda_stream)
-                pending[b] = sharding.post_gather(dist, rank, world, bounds, W, S, root_frame=frames[b])
-            else:
-                ctx.render_rows(params, mode, row0, rows, d_out=slabs[b].data_ptr(), out_row_base=row0,
-                                stream=stream.cuda_stream)
-                pending[b] = sharding.post_gather(dist, rank, world, bounds, W, S, slab=slabs[b])
+        def render(buf, r0, nrows, base):
+            # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
+            # RCCL transfers are ordered after.
+            ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
 
-        def drain():
-            for b in range(nbuf):
-                if pending[b] is not None:
-                    sharding.wait_all(pending[b])
-                    pending[b] = None
-
-        for i in range(Wm):
-            step(i)
-        drain()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(K):
-            step(i)
-        drain()
-        torch.cuda.synchronize()
-        dist.barrier()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        final = frames[(K - 1) % nbuf].cpu().numpy() if (args.verify and rank == 0) else None
+        elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
+        final = pipe.frame(K - 1).cpu().numpy() if (args.verify and rank == 0) else None
         # per-rank kernel time, measured apart from the pipeline, for the roofline object
         ctx.synchronize()
         ctx.timer_start()
         for _ in range(min(K, 50)):
-            ctx.render_rows(params, mode, row0, rows, d_out=(frames[0] if rank == 0 else slabs[0]).data_ptr(),
-                            out_row_base=0 if rank == 0 else row0)
+            ctx.render_rows(params, mode, row0, rows, d_out=pipe.bufs[0].data_ptr(), out_row_base=0 if rank == 0 else row0)
         kernel_ms = ctx.timer_stop() / min(K, 50)
 
     rays_per_frame = (W - 1) * H

@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
-    ap.add_argument("--what", default="trace", choices=["trace", "update"],
+    ap.add_argument("--what", default="trace", choices=["trace", "update", "update-async"],
                     help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
     args = ap.parse_args()
@@ -120,6 +120,15 @@ def main():
 
             def step(i):
                 ctx.update(params, mode)
+        elif args.what == "update-async":
+            F = 1
+            hb = [ctx.host_alloc(frame_bytes) for _ in range(2)]
+            inflight = []
+
+            def step(i):
+                if len(inflight) == 2:
+                    ctx.update_end(inflight.pop(0))
+                inflight.append(ctx.update_begin(params, mode, hb[i % 2][0]))
         elif F == 1:
             def step(i):
                 ctx.render(params, mode)
@@ -144,6 +153,9 @@ def main():
         t0 = time.perf_counter()
         for i in range(K):
             step(i)
+        if args.what == "update-async":
+            while inflight:
+                ctx.update_end(inflight.pop(0))
         ctx.synchronize()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
@@ -154,7 +166,7 @@ def main():
             final = None
         # The dominant kernel on its own: launches one after the other on the context's stream, timed with
         # HIP events on that stream (this is what a rocprofv3 kernel trace of --frames-in-flight 1 shows).
-        if args.what == "update":
+        if args.what != "trace":
             kernel_ms = elapsed / K * 1e3
         else:
             Kr = max(10, min(K, 100))
@@ -258,7 +270,7 @@ def main():
                        "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs + RCCL p2p gather to rank 0" % n_gpus},
             "roofline": roofline, "cpu_baseline": cpu,
         }
-        if args.what == "update":
+        if args.what != "trace":
             out["metric"] = "Mrays/s through the whole Update (trace + minimise + D2H of the minimised stream); not the graded metric"
             out["roofline"] = None
         if not distributed and args.what == "trace":

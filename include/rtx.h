@@ -167,6 +167,14 @@ int rtx_update_objects(rtx_ctx* ctx, double dt);
 int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics,
                void* host_out, size_t* out_bytes);
 
+/* Pipelined form of rtx_update (the copy of frame k overlapped with the trace of frame k+1).
+ * rtx_update_begin queues physics, trace and minimise of a frame, waits for them, then starts the copy of the
+ * minimised stream into host_out (pinned memory from rtx_host_alloc for full PCIe rate) on a separate stream and
+ * returns a ticket; rtx_update_end(ticket) waits for that copy and reports its length.  At most two frames may
+ * be in flight; host_out must stay valid and unread until rtx_update_end. */
+int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics, void* host_out, int* ticket);
+int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes);
+
 /* ---- pinned host memory for the buffers Update copies into (m_minimizedResultArray / m_hostResultArray,
  * RayTracingManager.cu:62-66, which the reference allocates pageable): device-to-host copies into it run at
  * PCIe rate instead of through a staging bounce.  Optional: any host pointer is accepted by rtx_update. */

@@ -68,6 +68,8 @@ _SIGNATURES = [
     ("rtx_minimized_device_ptr", _P, [_P]),
     ("rtx_update_objects", C.c_int, [_P, C.c_double]),
     ("rtx_update", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_size_t)]),
+    ("rtx_update_begin", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_int)]),
+    ("rtx_update_end", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
     ("rtx_host_alloc", _P, [_P, C.c_size_t]),
     ("rtx_host_free", None, [_P, _P]),
     ("rtx_timer_start", C.c_int, [_P]),
@@ -328,6 +330,26 @@ class Context:
         n = C.c_size_t()
         self._check(lib().rtx_update(self._h, C.byref(params), mode, dt, 1 if run_physics else 0, ptr, C.byref(n)))
         return arr[:n.value]  # a view of the pinned buffer: valid until the next update()
+
+    def host_alloc(self, nbytes):
+        """Pinned host buffer as (pointer, uint8 numpy view); freed with host_free or at close()."""
+        p = lib().rtx_host_alloc(self._h, nbytes)
+        if not p:
+            raise RtxError(ERR_OUT_OF_MEMORY, "rtx_host_alloc")
+        return p, np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def host_free(self, p):
+        lib().rtx_host_free(self._h, p)
+
+    def update_begin(self, params, mode, host_ptr, dt=0.0, run_physics=False):
+        t = C.c_int()
+        self._check(lib().rtx_update_begin(self._h, C.byref(params), mode, dt, 1 if run_physics else 0, host_ptr, C.byref(t)))
+        return t.value
+
+    def update_end(self, ticket):
+        n = C.c_size_t()
+        self._check(lib().rtx_update_end(self._h, ticket, C.byref(n)))
+        return n.value
 
     # -- timing on the context's stream
     def timer_start(self):

@@ -54,6 +54,23 @@ struct rtx_ctx {
     };
     std::vector<CellScratch> cell_scratch;
 
+    // pipelined Update (rtx_update_begin / rtx_update_end): two slots, each with its own frame, minimise
+    // buffer, scan scratch and events; the copy of slot k's stream to the host runs on copy_stream while slot
+    // k^1 is being traced
+    struct UpdateSlot {
+        uint8_t* d_frame = nullptr;
+        uint8_t* d_min = nullptr;
+        void* d_scan = nullptr;
+        size_t scan_bytes = 0;
+        uint64_t* h_total = nullptr; // pinned
+        hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
+        size_t bytes = 0;
+        bool busy = false;
+    };
+    UpdateSlot upd[2];
+    hipStream_t copy_stream = nullptr;
+    unsigned upd_next = 0;
+
     std::string error;
     const char* last_kernel = "";
 };

@@ -259,12 +259,12 @@ int ensure_min_buffers(rtx_ctx* ctx, size_t n_blocks, bool need_out)
     return RTX_OK;
 }
 
-int launch_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, uint64_t** d_total)
+int launch_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, uint64_t** d_total)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const size_t n_blocks = (size_t)((n_slots + rtx::kSlotsPerBlock - 1) / rtx::kSlotsPerBlock);
     // scratch layout: [total u64][offsets u64 x n_blocks][sums u32 x n_blocks]
-    uint64_t* total = (uint64_t*)ctx->d_scan;
+    uint64_t* total = (uint64_t*)d_scan;
     uint64_t* offsets = total + 8;
     uint32_t* sums = (uint32_t*)(offsets + n_blocks);
     const bool rgb = !(mode == RTX_BIT_ASCII || mode == RTX_BIT_PIXEL); // MinimizeResults, RayTracingManager.cu:167-179
@@ -323,7 +323,7 @@ int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, v
     if (rc != RTX_OK) return rc;
     if (!d_out) d_out = ctx->d_min;
     uint64_t* d_total = nullptr;
-    rc = launch_minimize(ctx, mode, w, h, (const uint8_t*)d_in, (uint8_t*)d_out, &d_total);
+    rc = launch_minimize(ctx, ctx->d_scan, mode, w, h, (const uint8_t*)d_in, (uint8_t*)d_out, &d_total);
     if (rc != RTX_OK) return rc;
     uint64_t total = 0;
     RTX_HIP(ctx, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
@@ -348,6 +348,76 @@ int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int 
         RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     *out_bytes = n;
+    return RTX_OK;
+}
+
+// ---- pipelined Update: the frame sequence of RayTracingManager::Update split in two calls so
+// that the copy of frame k's minimised stream to the host overlaps the trace of frame k+1.
+int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics, void* host_out, int* ticket)
+{
+    if (!ctx || !params || !host_out || !ticket) return RTX_ERR_INVALID_ARGUMENT;
+    if (mode < RTX_BIT_ASCII || mode > RTX_SDL) return rtx_fail(ctx, RTX_ERR_INVALID_MODE, "invalid rendering mode");
+    const size_t w = (size_t)params->x, h = (size_t)params->y;
+    if (w == 0 || h == 0 || 20 * w * h > ctx->capacity) return rtx_fail(ctx, RTX_ERR_TOO_LARGE, "frame larger than the context was created for");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned si = ctx->upd_next;
+    rtx_ctx::UpdateSlot& sl = ctx->upd[si];
+    if (sl.busy) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_update_begin: both slots are in flight; call rtx_update_end first");
+    if (!ctx->copy_stream) RTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!sl.d_frame) {
+        RTX_HIP(ctx, hipMalloc((void**)&sl.d_frame, ctx->capacity));
+        RTX_HIP(ctx, hipMemsetAsync(sl.d_frame, 0, ctx->capacity, ctx->stream));
+        RTX_HIP(ctx, hipMalloc((void**)&sl.d_min, ctx->capacity));
+        RTX_HIP(ctx, hipHostMalloc((void**)&sl.h_total, sizeof(uint64_t), hipHostMallocDefault));
+        RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming));
+        RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+    }
+    const uint64_t n_slots = (uint64_t)w * h;
+    const size_t n_blocks = (size_t)((n_slots + rtx::kSlotsPerBlock - 1) / rtx::kSlotsPerBlock);
+    const size_t need = n_blocks * (sizeof(uint32_t) + sizeof(uint64_t)) + 64;
+    if (sl.scan_bytes < need) {
+        if (sl.d_scan) hipFree(sl.d_scan);
+        sl.d_scan = nullptr;
+        sl.scan_bytes = 0;
+        RTX_HIP(ctx, hipMalloc(&sl.d_scan, need));
+        sl.scan_bytes = need;
+    }
+    int rc;
+    if (run_physics && (rc = rtx_update_objects(ctx, dt)) != RTX_OK) return rc;
+    // the slot's frame buffer is caller-style memory for rtx_render_rows: whole frame, with the zero
+    // semantics of the per-frame memset (the buffer starts zeroed; SDL frames write nothing, so clear)
+    const bool rgb = mode >= RTX_RGB_ASCII;
+    if (mode == RTX_SDL) {
+        RTX_HIP(ctx, hipMemsetAsync(sl.d_frame, 0, 20 * w * h, ctx->stream));
+    }
+    if ((rc = rtx_render_rows(ctx, params, mode, 0, h, sl.d_frame, 0, ctx->stream, rgb ? RTX_RENDER_DEFAULT : RTX_RENDER_ZERO_TAIL)) != RTX_OK) return rc;
+    uint64_t* d_total = nullptr;
+    if ((rc = launch_minimize(ctx, sl.d_scan, mode, w, h, sl.d_frame, sl.d_min, &d_total)) != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemcpyAsync(sl.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipEventRecord(sl.ev_ready, ctx->stream));
+    // the length is needed on the host to size the copy: wait for this frame's kernels (the previous frame's
+    // copy keeps running on the copy stream meanwhile)
+    RTX_HIP(ctx, hipEventSynchronize(sl.ev_ready));
+    sl.bytes = (size_t)*sl.h_total;
+    if (sl.bytes) {
+        RTX_HIP(ctx, hipMemcpyAsync(host_out, sl.d_min, sl.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    }
+    RTX_HIP(ctx, hipEventRecord(sl.ev_copied, ctx->copy_stream));
+    sl.busy = true;
+    *ticket = (int)si;
+    ctx->upd_next = si ^ 1u;
+    return RTX_OK;
+}
+
+int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes)
+{
+    if (!ctx || !out_bytes || ticket < 0 || ticket > 1) return RTX_ERR_INVALID_ARGUMENT;
+    rtx_ctx::UpdateSlot& sl = ctx->upd[ticket];
+    if (!sl.busy) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_update_end: no frame in flight under this ticket");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    RTX_HIP(ctx, hipEventSynchronize(sl.ev_copied));
+    *out_bytes = sl.bytes;
+    sl.busy = false;
     return RTX_OK;
 }
 

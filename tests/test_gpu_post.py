@@ -217,3 +217,39 @@ def test_pinned_host_buffer_roundtrip(R, ctx):
     a = np.array(ctx.update(p, R.RGB_PIXEL), copy=True)
     b = np.array(ctx.update(p, R.RGB_PIXEL), copy=True)
     assert a.size > 0 and np.array_equal(a, b)
+
+
+def test_pipelined_update_matches_synchronous_update(R, ctx):
+    """rtx_update_begin/_end with two frames in flight (copy of frame k overlapping the trace of k+1) must
+    deliver, frame by frame, the bytes of the synchronous Update, physics included."""
+    ctx.set_reference_default_scene()
+    sc = O.Scene.reference_default()
+    p = R.camera_params(400, 150)
+    nbytes = 20 * 400 * 150
+    bufs = [ctx.host_alloc(nbytes) for _ in range(2)]
+    try:
+        want = []
+        for k in range(5):
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, 0.04)
+            mode = [R.RGB_ASCII, R.BIT_ASCII, R.RGB_PIXEL, R.SDL, R.BIT_PIXEL][k]
+            frame = O.render(U.oracle_params(p), sc, mode)
+            want.append(O.minimize(mode, frame, 400, 150))
+        tickets = []
+        got = []
+        for k in range(5):
+            mode = [R.RGB_ASCII, R.BIT_ASCII, R.RGB_PIXEL, R.SDL, R.BIT_PIXEL][k]
+            if len(tickets) == 2:  # two in flight: retire the older one
+                t, idx = tickets.pop(0)
+                n = ctx.update_end(t)
+                got.append(np.array(bufs[idx][1][:n], copy=True))
+            t = ctx.update_begin(p, mode, bufs[k % 2][0], dt=0.04, run_physics=True)
+            tickets.append((t, k % 2))
+        for t, idx in tickets:
+            n = ctx.update_end(t)
+            got.append(np.array(bufs[idx][1][:n], copy=True))
+        assert len(got) == 5
+        for k in range(5):
+            assert np.array_equal(got[k], want[k]), k
+    finally:
+        for ptr, _ in bufs:
+            ctx.host_free(ptr)

@@ -263,16 +263,4 @@ __device__ __forceinline__ uint32_t ansi256_from_rgb(uint32_t r, uint32_t g, uin
     return cube_distance < grey_distance ? 16u + 36u * ir + 6u * ig + ib : grey_index;
 }
 
-// Three decimal digits with NUL for absent leading digits (RayTracing.cu:212-229 and its
-// copies; equal to plain decimal for 0..255).  Returns d0 | d1 << 8 | d2 << 16.
-__device__ __forceinline__ uint32_t digits3(uint32_t v)
-{
-    const uint32_t h = v / 100u;
-    const uint32_t t = (v / 10u) % 10u;
-    const uint32_t u = v % 10u;
-    const uint32_t d0 = v >= 100u ? 48u + h : 0u;
-    const uint32_t d1 = v >= 10u ? 48u + t : 0u;
-    return d0 | (d1 << 8) | ((48u + u) << 16);
-}
-
 } // namespace rtx

@@ -56,6 +56,20 @@ __constant__ const char kRamp[68] = {
     'k', 'h', 'a', 'o', '#', '%', 'Z', 'O', '8', 'B', '$', '0', 'Q', 'M', '&', 'W', '@'
 };
 
+// Three decimal digits of 0..255, NUL padded (RayTracing.cu:212-229): d0 | d1 << 8 | d2 << 16, built at compile time.
+struct DigitsTable {
+    uint32_t v[256];
+    constexpr DigitsTable() : v()
+    {
+        for (uint32_t i = 0; i < 256u; i++) {
+            const uint32_t d0 = i >= 100u ? 48u + i / 100u : 0u;
+            const uint32_t d1 = i >= 10u ? 48u + (i / 10u) % 10u : 0u;
+            v[i] = d0 | (d1 << 8) | ((48u + i % 10u) << 16);
+        }
+    }
+};
+__constant__ const DigitsTable kDigits = DigitsTable();
+
 // Conservative inflation of a sphere for culling.  A ray whose fp32 test reports a hit passes, in exact
 // arithmetic, within R of the centre with R^2 = r^2 (1+2u) + 15.2u |otc|^2 (u = 2^-24; derivation in
 // DESIGN.md "Culling soundness"), and no further than 3u|otc| behind the apex.  kappa = 2e-6 is 2.2x
@@ -130,6 +144,34 @@ __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float
         out = out || (d > margin);
     }
     return out;
+}
+
+// One plane of the same pyramid, selected by k: 0..3 the side through corners k and k+1 (corner order
+// (x0,y0) (x1,y0) (x1,y1) (x0,y1)), 4 the axis plane.  Same arithmetic as tile_frustum, arranged so that five
+// lanes can compute the five planes side by side.
+__device__ __forceinline__ V3 tile_plane(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, uint32_t k)
+{
+    const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
+    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
+    const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
+    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;
+    const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;
+    const uint32_t ka = k & 3u, kb = (k + 1u) & 3u;
+    const float xa = (ka == 1u || ka == 2u) ? x1 : x0, ya = ka >= 2u ? y1 : y0;
+    const float xb = (kb == 1u || kb == 2u) ? x1 : x0, yb = kb >= 2u ? y1 : y0;
+    const V3 va = view_dir(c, xa, ya), vb = view_dir(c, xb, yb);
+    const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
+    V3 n = k < 4u ? cross(va, vb) : axis;
+    float side = dot(n, axis);
+    if (!(side > 0.0f)) {
+        n = mulf(n, -1.0f);
+        side = -side;
+    }
+    const float len2 = dot(n, n);
+    if (side > 0.0f && len2 > 1.0e-30f && len2 < 1.0e30f) {
+        return mulf(n, __builtin_amdgcn_rsqf(len2));
+    }
+    return v3(0.0f, 0.0f, 0.0f);
 }
 
 struct Best {
@@ -402,7 +444,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     float4 g0 = load_item(items, tid, k0), g1 = load_item(items, kThreads + tid, k1);
 
     // ---- per-workgroup tables (visible after the first barrier below)
-    s_digits[tid] = digits3(tid);
+    s_digits[tid] = kDigits.v[tid];
     if (tid < 68u) {
         s_ramp[tid] = (uint8_t)kRamp[tid];
     }
@@ -434,14 +476,12 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
     TileFrustum fr;
     if (CULL) {
         if (tid < 64u) {
-            const TileFrustum f0 = tile_frustum(cam, mcol0, mrow0, mw, mh);
-            if (tid == 0u) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    s_frustum[3 * k + 0] = f0.n[k].x;
-                    s_frustum[3 * k + 1] = f0.n[k].y;
-                    s_frustum[3 * k + 2] = f0.n[k].z;
-                }
+            // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along)
+            const V3 n = tile_plane(cam, mcol0, mrow0, mw, mh, tid);
+            if (tid < 5u) {
+                s_frustum[3 * tid + 0] = n.x;
+                s_frustum[3 * tid + 1] = n.y;
+                s_frustum[3 * tid + 2] = n.z;
             }
         }
         lds_barrier();

@@ -386,3 +386,29 @@ def test_many_planes_beyond_the_lds_table(R, ctx):
         set_kernel(R, ctx, kernel)
         got = ctx.render_to_host(p, R.RGB_ASCII)
         assert_same(got, want, O.RGB_ASCII, 320, "40 planes %s" % kernel)
+
+
+@pytest.mark.parametrize("res", [(333, 77), (1025, 3), (7, 513), (2049, 5), (64, 64), (129, 257)])
+def test_odd_frame_sizes_with_culling(R, ctx, res):
+    """Frame sizes that are not multiples of any tile dimension, with enough spheres for the binned kernel
+    and (forced) two-level culling; full frames and ragged row slabs."""
+    import torch
+    w, h = res
+    p = R.camera_params(w, h, (1.0, 2.0, -3.0), (0.1, 3.0, 0.0))
+    sph, pl = R.synth_scene(77, 300, 2, p.element1, p.element2)
+    ctx.set_scene(sph, pl)
+    sc = O.Scene.from_arrays(sph, pl)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=4)
+    for two in (0, 1):
+        for sub in (0, 1, 3):
+            set_kernel(R, ctx, "binned", 0, sub, two)
+            got = ctx.render_to_host(p, R.RGB_ASCII)
+            assert_same(got, want, O.RGB_ASCII, w, "%dx%d two-level %d sub %d" % (w, h, two, sub))
+    set_kernel(R, ctx, "binned", two_level=1)
+    dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    cuts = sorted(set([0, h // 3, h // 2 + 1 if h > 2 else h, h]))
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        ctx.render_rows(p, R.RGB_ASCII, r0, r1 - r0, d_out=dst.data_ptr(), out_row_base=0)
+    ctx.synchronize()
+    assert_same(dst.cpu().numpy(), want, O.RGB_ASCII, w, "%dx%d slabs" % (w, h))

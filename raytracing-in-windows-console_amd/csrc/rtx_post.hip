@@ -8,7 +8,7 @@
 namespace rtx {
 
 constexpr int kThreads = 256;
-constexpr int kItems = 8;                      // slots per thread
+constexpr int kItems = 2;                      // slots per thread
 constexpr int kSlotsPerBlock = kThreads * kItems;
 
 // ---------------------------------------------------------------- UpdateObjects
@@ -131,18 +131,110 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s
     return base + incl - v;
 }
 
+// ---- staged form.  A block owns kSlotsPerBlock consecutive slots.  Its input bytes (plus a halo of the two
+// slots before it, which is where the previous ESC slot of a rendered frame always is) are brought into
+// LDS with coalesced 16-byte loads; slots are then read from LDS at their 12/20-byte stride (5 or 3 dwords:
+// odd strides are bank-conflict free).  The scatter kernel also builds its output bytes in LDS and writes
+// them out with aligned 16-byte stores, so that HBM sees only full-width traffic.
+constexpr int kHaloOff = 48; // LDS byte offset of the block's first slot: 16-byte aligned, room for 2 x 20 halo bytes
+
+template <int S>
+__device__ __forceinline__ void stage_input(const uint8_t* __restrict__ in, uint64_t first_slot, uint64_t n_slots, uint8_t* s_in)
+{
+    const uint64_t b0 = first_slot * S;
+    const uint64_t total_bytes = n_slots * S;
+    const uint64_t b1 = b0 + (uint64_t)kSlotsPerBlock * S < total_bytes ? b0 + (uint64_t)kSlotsPerBlock * S : total_bytes;
+    const uint32_t nbytes = (uint32_t)(b1 - b0);           // multiple of 4
+    const uint32_t n16 = nbytes / 16u;
+    const uint4* src = reinterpret_cast<const uint4*>(in + b0);
+    uint4* dst = reinterpret_cast<uint4*>(s_in + kHaloOff);
+    for (uint32_t i = threadIdx.x; i < n16; i += kThreads) {
+        dst[i] = src[i];
+    }
+    // tail dwords (when the frame ends inside this block) and the halo
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(in + b0);
+    uint32_t* dst32 = reinterpret_cast<uint32_t*>(s_in + kHaloOff);
+    for (uint32_t i = n16 * 4u + threadIdx.x; i < nbytes / 4u; i += kThreads) {
+        dst32[i] = src32[i];
+    }
+    if (threadIdx.x < 2u * S / 4u) {
+        const uint32_t hd = threadIdx.x; // dword of the halo, counted from its start
+        uint32_t v = 0u;
+        if (b0 >= 2u * S) {
+            v = reinterpret_cast<const uint32_t*>(in + b0 - 2u * S)[hd];
+        } else if (b0 >= S && hd >= S / 4u) {
+            v = reinterpret_cast<const uint32_t*>(in + b0 - S)[hd - S / 4u];
+        }
+        reinterpret_cast<uint32_t*>(s_in + kHaloOff - 2 * S)[hd] = v;
+    }
+}
+
+template <int S>
+__device__ __forceinline__ Slot<S> lds_slot(const uint8_t* s_in, int li)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(s_in + kHaloOff + li * S);
+    Slot<S> r;
+#pragma unroll
+    for (int k = 0; k < S / 4; k++) {
+        r.w[k] = p[k];
+    }
+    return r;
+}
+
+// Emitted length of global slot g = first_slot + li, whose bytes (and halo) are staged in LDS.
+template <int S>
+__device__ __forceinline__ uint32_t staged_length(const uint8_t* in, const uint8_t* s_in, uint64_t g, int li, uint32_t col, uint32_t W, Slot<S>& rec)
+{
+    if (col == W - 1u) {
+        return 1u; // newline
+    }
+    rec = lds_slot<S>(s_in, li);
+    if ((rec.w[0] & 0xffu) != 0x1bu) {
+        return 0u;
+    }
+    if (g == 0) {
+        return (uint32_t)S; // first pixel of the frame
+    }
+    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's NUL column
+    const int back = col == 0u ? 2 : 1;
+    if (g >= (uint64_t)back) {
+        const Slot<S> prev = lds_slot<S>(s_in, li - back);
+        if ((prev.w[0] & 0xffu) == 0x1bu) {
+            return same_colour<S>(rec, prev) ? 1u : (uint32_t)S;
+        }
+    }
+    // not a fully rendered frame (empty slots in between): walk back through global memory
+    uint64_t j = g;
+    while (j > 0) {
+        --j;
+        if ((uint32_t)(j % W) == W - 1u) {
+            continue;
+        }
+        if (in[j * S] == 0x1bu) {
+            const Slot<S> prev = load_slot<S>(in, j);
+            return same_colour<S>(rec, prev) ? 1u : (uint32_t)S;
+        }
+    }
+    return (uint32_t)S;
+}
+
 template <int S>
 __global__ __launch_bounds__(kThreads) void rtx_min_count(const uint8_t* in, uint64_t n_slots, uint32_t W, uint32_t* block_sums)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kSlotsPerBlock * S];
     __shared__ uint32_t s_wave[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kSlotsPerBlock;
+    stage_input<S>(in, base, n_slots, s_in);
+    const uint32_t col0 = (uint32_t)(base % W); // one 64-bit division per thread; columns below are 32-bit
+    __syncthreads();
     uint32_t sum = 0;
 #pragma unroll
     for (int it = 0; it < kItems; it++) {
-        const uint64_t i = base + (uint64_t)it * kThreads + threadIdx.x;
-        if (i < n_slots) {
+        const int li = it * kThreads + (int)threadIdx.x;
+        const uint64_t g = base + (uint64_t)li;
+        if (g < n_slots) {
             Slot<S> rec;
-            sum += slot_length<S>(in, i, W, rec);
+            sum += staged_length<S>(in, s_in, g, li, (col0 + (uint32_t)li) % W, W, rec);
         }
     }
     uint32_t total;
@@ -152,69 +244,52 @@ __global__ __launch_bounds__(kThreads) void rtx_min_count(const uint8_t* in, uin
     }
 }
 
-// Exclusive scan of the per-block sums (one workgroup), total length to *total_out.
-__global__ __launch_bounds__(1024) void rtx_min_scan_blocks(const uint32_t* block_sums, uint64_t* block_offsets, uint32_t n_blocks, uint64_t* total_out)
-{
-    __shared__ uint64_t s_wave[16];
-    __shared__ uint64_t s_carry;
-    if (threadIdx.x == 0) {
-        s_carry = 0;
-    }
-    __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < n_blocks; base += 1024u) {
-        const uint32_t i = base + threadIdx.x;
-        const uint64_t v = i < n_blocks ? (uint64_t)block_sums[i] : 0ull;
-        uint64_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t o = __shfl_up(incl, d);
-            if (lane >= (uint32_t)d) {
-                incl += o;
-            }
-        }
-        if (lane == 63u) {
-            s_wave[wave] = incl;
-        }
-        __syncthreads();
-        uint64_t before = 0, total = 0;
-        for (uint32_t k = 0; k < 16u; k++) {
-            const uint64_t t = s_wave[k];
-            before += k < wave ? t : 0ull;
-            total += t;
-        }
-        const uint64_t carry = s_carry;
-        if (i < n_blocks) {
-            block_offsets[i] = carry + before + incl - v;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_carry = carry + total;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *total_out = s_carry;
-    }
-}
-
 template <int S>
-__global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, uint64_t n_slots, uint32_t W, const uint64_t* block_offsets, uint8_t* out)
+__global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, uint64_t n_slots, uint32_t W, const uint32_t* block_sums, uint8_t* out, uint64_t* total_out)
 {
+    __shared__ uint64_t s_part[kThreads / 64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kSlotsPerBlock * S];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 + kSlotsPerBlock * S];
     __shared__ uint32_t s_wave[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kSlotsPerBlock;
-    uint64_t carry = block_offsets[blockIdx.x];
+    stage_input<S>(in, base, n_slots, s_in);
+    // where this block's output starts: the sum of the lengths of the blocks before it (a few KB of L2 reads
+    // per block; cheaper than a separate scan launch)
+    uint64_t part = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) {
+        part += block_sums[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += __shfl_xor(part, d);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_part[threadIdx.x >> 6] = part;
+    }
+    __syncthreads();
+    uint64_t G = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; k++) {
+        G += s_part[k];
+    }
+    const uint32_t pad = (uint32_t)(G & 15u);     // the LDS image is laid out with the same 16-byte phase
+    const uint32_t col0 = (uint32_t)(base % W);
+    __syncthreads();
+
+    uint32_t carry = 0;
 #pragma unroll 1
     for (int it = 0; it < kItems; it++) {
-        const uint64_t i = base + (uint64_t)it * kThreads + threadIdx.x;
+        const int li = it * kThreads + (int)threadIdx.x;
+        const uint64_t g = base + (uint64_t)li;
         Slot<S> rec;
         uint32_t len = 0;
-        if (i < n_slots) {
-            len = slot_length<S>(in, i, W, rec);
+        const uint32_t col = (col0 + (uint32_t)li) % W;
+        if (g < n_slots) {
+            len = staged_length<S>(in, s_in, g, li, col, W, rec);
         }
         uint32_t total;
         const uint32_t excl = block_exclusive_scan(len, s_wave, total);
-        uint8_t* dst = out + carry + excl;
+        uint8_t* dst = s_out + pad + carry + excl;
         if (len == (uint32_t)S) {
 #pragma unroll
             for (int k = 0; k < S / 4; k++) {
@@ -225,10 +300,32 @@ __global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, u
                 dst[4 * k + 3] = (uint8_t)(w >> 24);
             }
         } else if (len == 1u) {
-            const bool newline = (uint32_t)(i % W) == W - 1u;
+            const bool newline = col == W - 1u;
             dst[0] = newline ? (uint8_t)'\n' : (uint8_t)(rec.w[S / 4 - 1] >> 24);
         }
         carry += total;
+    }
+    __syncthreads();
+
+    // copy out: bytes [G, G + carry).  Head up to the first 16-byte boundary and tail after the last one go
+    // out byte by byte (neighbouring blocks own the other bytes of those 16-byte lines); the body as uint4.
+    const uint32_t n = carry;
+    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
+    const uint32_t body16 = (n - head) / 16u;
+    const uint32_t tail = n - head - body16 * 16u;
+    if (threadIdx.x < head) {
+        out[G + threadIdx.x] = s_out[pad + threadIdx.x];
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(s_out + pad + head); // pad + head is 0 mod 16
+    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
+    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
+        dst16[i] = src[i];
+    }
+    if (threadIdx.x < tail) {
+        out[G + head + body16 * 16u + threadIdx.x] = s_out[pad + head + body16 * 16u + threadIdx.x];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total_out = G + n; // length of the minimised stream
     }
 }
 
@@ -274,11 +371,10 @@ int launch_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, co
     } else {
         hipLaunchKernelGGL((rtx::rtx_min_count<12>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_in, n_slots, (uint32_t)w, sums);
     }
-    hipLaunchKernelGGL(rtx::rtx_min_scan_blocks, dim3(1), dim3(1024), 0, st, sums, offsets, (uint32_t)n_blocks, total);
     if (rgb) {
-        hipLaunchKernelGGL((rtx::rtx_min_scatter<20>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_in, n_slots, (uint32_t)w, offsets, d_out);
+        hipLaunchKernelGGL((rtx::rtx_min_scatter<20>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_in, n_slots, (uint32_t)w, sums, d_out, total);
     } else {
-        hipLaunchKernelGGL((rtx::rtx_min_scatter<12>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_in, n_slots, (uint32_t)w, offsets, d_out);
+        hipLaunchKernelGGL((rtx::rtx_min_scatter<12>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_in, n_slots, (uint32_t)w, sums, d_out, total);
     }
     RTX_HIP(ctx, hipGetLastError());
     *d_total = total;
@@ -314,7 +410,9 @@ int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, v
         if (20 * w * h > ctx->capacity) return rtx_fail(ctx, RTX_ERR_TOO_LARGE, "frame larger than the context was created for");
         d_in = ctx->d_frame;
     }
-    if (((uintptr_t)d_in & 3u) != 0) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "input frame must be 4-byte aligned");
+    if (((uintptr_t)d_in & 15u) != 0 || (d_out && ((uintptr_t)d_out & 15u) != 0)) {
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "minimise buffers must be 16-byte aligned");
+    }
     RTX_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n_slots = (uint64_t)w * h;
     const size_t n_blocks = (size_t)((n_slots + rtx::kSlotsPerBlock - 1) / rtx::kSlotsPerBlock);

@@ -139,3 +139,16 @@ def test_oracle_reproduces_committed_goldens_small():
         assert (O.fnv1a64(mini), mini.size) == (g["minimized_fnv1a64"], g["minimized_bytes"])
     frame = np.load(os.path.join(U.GOLDEN_DIR, "c1_rgb_ascii_frame.npz"))["frame"]
     assert np.array_equal(frame, O.render(op, sc, O.RGB_ASCII))
+
+
+def test_header_is_valid_c99_and_cxx():
+    """include/rtx.h is a C ABI: it must compile as C99 (examples/c_abi_demo.c uses it from plain C) and as
+    C++; rtx_compat.hpp as C++17."""
+    import subprocess
+    inc = os.path.join(U.ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
+                           os.path.join(U.ROOT, "examples", "c_abi_demo.c")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
+                           os.path.join(U.ROOT, "examples", "headless_engine.cpp")])
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
+                           os.path.join(U.ROOT, "examples", "console_demo.cpp")])

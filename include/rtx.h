@@ -138,7 +138,9 @@ int rtx_render_rows(rtx_ctx* ctx, const rtx_params* params, int mode, size_t row
 /* Queues n whole frames with one call (a renderer keeping several frames in flight): frame i is traced with
  * params[i] into d_outs[i] (each a 20*W*H device buffer of the caller) on streams[i] (hipStream_t).  Frames
  * queued on different streams with different buffers may execute concurrently; on one stream they run in
- * order.  Asynchronous; the caller synchronises its streams.  Same effect as n rtx_render_rows calls. */
+ * order.  Asynchronous; the caller synchronises its streams.  Same effect as n rtx_render_rows calls.
+ * Scene changes (rtx_scene_add_*, rtx_update_objects, rtx_scene_clear) must not race with frames in flight on
+ * other streams: synchronise those streams first. */
 int rtx_submit_frames(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode, void* const* d_outs, void* const* streams);
 
 int rtx_synchronize(rtx_ctx* ctx);

@@ -13,11 +13,13 @@ buffer resident in HBM at the end.  rays per frame = (W-1)*H (RayTracing.cu:187)
 N = 1: each frame is rendered by one launch; by default 4 frames are in flight on 4 HIP streams (frame i in
        frame buffer i % 4), because consecutive frames are independent and the drain of one launch overlaps
        the ramp of the next.  --frames-in-flight 1 renders strictly one after the other.
-N > 1: the frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H/N) with the global
-       row index in ray generation) and assembled on rank 0 by RCCL point-to-point transfers over
-       xGMI, each peer's slab landing directly at its offset of the root's frame buffer.  Total
-       work is fixed as N grows ("strong").  Frames are double-buffered so that the transfer of
-       frame k overlaps the trace of frame k+1; all K frames are complete inside the timed region.
+N > 1: every frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H/N) with the global
+       row index in ray generation) and assembled on its root GPU by RCCL point-to-point transfers over
+       xGMI, each peer's slab landing directly at its offset of the root's frame buffer.  The root
+       rotates (frame i on rank i % N; --root fixed pins it to rank 0), so that every GPU's inbound links
+       carry one frame in N.  Total work is fixed as N grows ("strong").  Buffers are rings, so the
+       transfers of a frame overlap the trace of the next ones; all K frames are complete (whole frame
+       resident in its root's HBM) inside the timed region.
 
 Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the fp32-VALU
 view, since the brute-force form of this path is VALU-bound) and "cpu_baseline" (the CPU oracle --
@@ -64,6 +66,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="check the assembled frame against the golden hash")
+    ap.add_argument("--root", default="rotate", choices=["rotate", "fixed"],
+                    help="N>1: frame i is assembled on rank i %% N (rotate) or always on rank 0 (fixed)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
@@ -180,7 +184,7 @@ def main():
     else:
         import torch.distributed as dist
         stream = torch.cuda.current_stream()
-        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2)
+        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
 
         def render(buf, r0, nrows, base):
             # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
@@ -188,12 +192,26 @@ def main():
             ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
 
         elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
-        final = pipe.frame(K - 1).cpu().numpy() if (args.verify and rank == 0) else None
+        final = None
+        if args.verify:
+            # the last frame sits on its root; rank 0 reports, so ship the hash-relevant bytes there
+            last_root = pipe.root_of(K - 1)
+            if rank == last_root:
+                buf = pipe.frame(K - 1)
+                if last_root != 0:
+                    dist.send(buf, 0)
+                else:
+                    final = buf.cpu().numpy()
+            elif rank == 0:
+                buf = torch.empty(frame_bytes, dtype=torch.uint8, device="cuda")
+                dist.recv(buf, last_root)
+                final = buf.cpu().numpy()
         # per-rank kernel time, measured apart from the pipeline, for the roofline object
         ctx.synchronize()
         ctx.timer_start()
         for _ in range(min(K, 50)):
-            ctx.render_rows(params, mode, row0, rows, d_out=pipe.bufs[0].data_ptr(), out_row_base=0 if rank == 0 else row0)
+            tgt = pipe.slabs[0] if pipe.slabs is not None else pipe.frames[0]
+            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if pipe.slabs is not None else 0)
         kernel_ms = ctx.timer_stop() / min(K, 50)
 
     rays_per_frame = (W - 1) * H
@@ -267,7 +285,8 @@ def main():
             "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
                                    % (args.config, W, H, ns, npl, args.mode, seed),
                        "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel,
-                       "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs + RCCL p2p gather to rank 0" % n_gpus},
+                       "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs + RCCL p2p gather; frame i assembled on rank %s"
+                                      % (n_gpus, "i %% N" if args.root == "rotate" else "0")},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.what != "trace":

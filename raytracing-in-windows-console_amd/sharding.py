@@ -40,54 +40,93 @@ def wait_all(reqs):
 
 
 class RowShardedFrames:
-    """The N > 1 frame loop of bench.py: every rank renders its row slab, rank 0 assembles the frame.
+    """The N > 1 frame loop of bench.py: every rank renders its row slab of every frame, and the frame is
+    assembled on its root rank by point-to-point transfers.
 
-    Buffers are a ring of `nbuf` (rank 0: whole frames, in which it renders its own rows in place; peers:
-    slabs), so that the transfer of frame i overlaps the rendering of frame i+1.  `render(buffer, row0, rows,
-    out_row_base)` must queue the rendering of rows [row0, row0+rows) into `buffer`, whose first byte is row
-    `out_row_base`, on the stream (or thread) the transfers are ordered after -- torch's current stream on
-    GPUs.  Device-agnostic: the CPU tests drive it over gloo with the oracle as renderer."""
+    `rotate_root=True` (default): frame i is assembled on rank i % N, so that successive frames converge on
+    different GPUs: every GPU's inbound xGMI links carry one frame in N instead of rank 0's carrying all of
+    them, and each finished frame sits next to its own PCIe link to the host.  `rotate_root=False`: every
+    frame is assembled on rank 0.
 
-    def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2):
+    Buffers: a ring of `nbuf` whole frames (used when this rank is the root; it renders its own rows in
+    place) and a ring of `nbuf` slabs (used otherwise), so the transfers of a frame overlap the rendering of
+    the next ones.  `render(buffer, row0, rows, out_row_base)` must queue the rendering of rows
+    [row0, row0+rows) into `buffer`, whose first byte is row `out_row_base`, on the stream (or thread) the
+    transfers are ordered after -- torch's current stream on GPUs.  Device-agnostic: the CPU tests drive it
+    over gloo with the oracle as renderer."""
+
+    def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2, rotate_root=True):
         self.dist, self.rank, self.world = dist, rank, world
         self.W, self.H, self.S, self.nbuf = width, height, record_size, nbuf
+        self.rotate = rotate_root
         self.bounds = row_bounds(height, world)
         self.row0 = self.bounds[rank]
         self.rows = self.bounds[rank + 1] - self.bounds[rank]
-        if rank == 0:
+        self.frames = None
+        if rank == 0 or rotate_root:
             # 20*W*H bytes each: the reference's frame size whatever the mode (PrintMachine.cpp:140)
-            self.bufs = [torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        else:
-            self.bufs = [torch.zeros(record_size * width * self.rows, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        self.pending = [None] * nbuf
+            self.frames = [torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.slabs = None
+        if rank != 0 or rotate_root:
+            self.slabs = [torch.zeros(max(1, record_size * width * self.rows), dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.pending_frame = [None] * nbuf
+        self.pending_slab = [None] * nbuf
+        self.n_root = 0   # frames this rank has been root of
+        self.n_peer = 0   # frames this rank has sent a slab for
+        self.where = {}   # frame number -> frame ring index (root frames only)
+
+    def root_of(self, i):
+        return i % self.world if self.rotate else 0
 
     def step(self, i, render):
-        b = i % self.nbuf
-        if self.pending[b] is not None:  # the transfer that last used this buffer
-            wait_all(self.pending[b])
-            self.pending[b] = None
-        if self.rank == 0:
-            render(self.bufs[b], self.row0, self.rows, 0)
-            self.pending[b] = post_gather(self.dist, 0, self.world, self.bounds, self.W, self.S, root_frame=self.bufs[b])
+        root = self.root_of(i)
+        if root == self.rank:
+            b = self.n_root % self.nbuf
+            self.n_root += 1
+            if self.pending_frame[b] is not None:  # the transfers that last used this frame buffer
+                wait_all(self.pending_frame[b])
+                self.pending_frame[b] = None
+            render(self.frames[b], self.row0, self.rows, 0)
+            ops = []
+            for g in range(self.world):
+                lo, hi = self.bounds[g] * self.W * self.S, self.bounds[g + 1] * self.W * self.S
+                if g != self.rank and hi > lo:
+                    ops.append(self.dist.P2POp(self.dist.irecv, self.frames[b][lo:hi], g))
+            self.pending_frame[b] = self.dist.batch_isend_irecv(ops) if ops else []
+            self.where[i] = b
         else:
-            render(self.bufs[b], self.row0, self.rows, self.row0)
-            self.pending[b] = post_gather(self.dist, self.rank, self.world, self.bounds, self.W, self.S, slab=self.bufs[b])
+            b = self.n_peer % self.nbuf
+            self.n_peer += 1
+            if self.pending_slab[b] is not None:
+                wait_all(self.pending_slab[b])
+                self.pending_slab[b] = None
+            render(self.slabs[b], self.row0, self.rows, self.row0)
+            n = self.S * self.W * self.rows
+            self.pending_slab[b] = self.dist.batch_isend_irecv(
+                [self.dist.P2POp(self.dist.isend, self.slabs[b][:n], root)]) if n else []
 
     def drain(self):
-        for b in range(self.nbuf):
-            if self.pending[b] is not None:
-                wait_all(self.pending[b])
-                self.pending[b] = None
+        for ring in (self.pending_frame, self.pending_slab):
+            for b in range(self.nbuf):
+                if ring[b] is not None:
+                    wait_all(ring[b])
+                    ring[b] = None
 
     def frame(self, i):
-        """Rank 0: the buffer frame i was assembled in (valid after drain())."""
-        return self.bufs[i % self.nbuf]
+        """On the root of frame i: the buffer it was assembled in (valid after drain() and until nbuf more
+        frames have been rooted here)."""
+        return self.frames[self.where[i]]
 
 
 def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize):
     """bench.py's timing contract for N > 1: warm-up, then exactly `steps` frames between barrier +
     synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
     import time
+    # communicator set-up (not a timed or counted step): one full rotation of roots, so that every pair of
+    # ranks that will exchange slabs has done so once
+    for i in range(pipe.world if pipe.rotate else 1):
+        pipe.step(i, render)
+    pipe.drain()
     for i in range(warmup):
         pipe.step(i, render)
     pipe.drain()

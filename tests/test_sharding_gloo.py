@@ -74,7 +74,7 @@ def test_row_bounds_cover_every_row_once():
             assert b[0] == 0 and b[-1] == H and all(b[i] <= b[i + 1] for i in range(world))
 
 
-def _pipeline_worker(rank, world, port, out_path):
+def _pipeline_worker(rank, world, port, rotate, out_path):
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.dirname(here)):
         if p not in sys.path:
@@ -89,7 +89,7 @@ def _pipeline_worker(rank, world, port, out_path):
         mode, S = O.RGB_ASCII, 20
         sc = O.Scene.from_arrays(sph, pl)
         op = U.oracle_params(p)
-        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cpu", nbuf=2)
+        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cpu", nbuf=2, rotate_root=rotate)
         calls = []
 
         def render(buf, r0, nrows, base):
@@ -99,18 +99,26 @@ def _pipeline_worker(rank, world, port, out_path):
             view[(r0 - base) * W * S:(r0 - base + nrows) * W * S] = full[r0 * W * S:(r0 + nrows) * W * S]
             calls.append((r0, nrows, base))
 
-        elapsed = sharding.timed_frames(dist, torch, pipe, render, steps=5, warmup=3, device="cpu", synchronize=lambda: None)
-        assert elapsed > 0 and len(calls) == 8
+        steps, warmup = 7, 2
+        elapsed = sharding.timed_frames(dist, torch, pipe, render, steps=steps, warmup=warmup, device="cpu", synchronize=lambda: None)
+        assert elapsed > 0 and len(calls) == steps + warmup + (world if rotate else 1)
+        want = O.render(op, sc, mode)
+        ok = 1
+        for i in (steps - 2, steps - 1):  # the last two frames, wherever they were assembled
+            if pipe.root_of(i) == rank:
+                ok &= int(np.array_equal(pipe.frame(i).numpy(), want))
+        t = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
         if rank == 0:
-            want = O.render(op, sc, mode)
-            ok = all(np.array_equal(pipe.frame(i).numpy(), want) for i in (3, 4))
-            np.save(out_path, np.array([int(ok)]))
+            np.save(out_path, np.array([int(t.item())]))
     finally:
         dist.destroy_process_group()
 
 
-def test_bench_frame_pipeline_over_gloo(tmp_path):
-    """The exact loop bench.py runs for --gpus N (RowShardedFrames + timed_frames), world_size 2, CPU tensors."""
+@pytest.mark.parametrize("world,rotate", [(2, True), (2, False), (3, True)])
+def test_bench_frame_pipeline_over_gloo(tmp_path, world, rotate):
+    """The exact loop bench.py runs for --gpus N (RowShardedFrames + timed_frames) over gloo with CPU tensors:
+    rotating and fixed roots."""
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_pipeline_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), rotate, out), nprocs=world, join=True)
     assert int(np.load(out)[0]) == 1

@@ -14,12 +14,13 @@ N = 1: each frame is rendered by one launch; by default 4 frames are in flight o
        frame buffer i % 4), because consecutive frames are independent and the drain of one launch overlaps
        the ramp of the next.  --frames-in-flight 1 renders strictly one after the other.
 N > 1: every frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H/N) with the global
-       row index in ray generation) and assembled on its root GPU by RCCL point-to-point transfers over
-       xGMI, each peer's slab landing directly at its offset of the root's frame buffer.  The root
-       rotates (frame i on rank i % N; --root fixed pins it to rank 0), so that every GPU's inbound links
-       carry one frame in N.  Total work is fixed as N grows ("strong").  Buffers are rings, so the
-       transfers of a frame overlap the trace of the next ones; all K frames are complete (whole frame
-       resident in its root's HBM) inside the timed region.
+       row index in ray generation) and assembled, complete, in the HBM of its root GPU.  The root rotates
+       (frame i on rank i % N), so every directed xGMI link carries one slab per N frames.  Default
+       (--exchange rounds): frames go in rounds of N; a rank queues its N slab launches of a round on
+       several streams and ONE RCCL all-to-all per round delivers slab j of every rank to rank j in row
+       order.  --exchange p2p: one point-to-point gather per frame (--root fixed pins the root to rank 0).
+       Total work is fixed as N grows ("strong").  Buffers are rings, so the exchange of a round overlaps
+       the trace of the next; all K frames are complete inside the timed region.
 
 Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the fp32-VALU
 view, since the brute-force form of this path is VALU-bound) and "cpu_baseline" (the CPU oracle --
@@ -68,6 +69,9 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the assembled frame against the golden hash")
     ap.add_argument("--root", default="rotate", choices=["rotate", "fixed"],
                     help="N>1: frame i is assembled on rank i %% N (rotate) or always on rank 0 (fixed)")
+    ap.add_argument("--exchange", default="rounds", choices=["rounds", "p2p"],
+                    help="N>1: rounds = frames in rounds of N with rotating roots and one RCCL all-to-all per round "
+                         "(default); p2p = one point-to-point gather per frame (see --root)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
@@ -83,7 +87,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_gpus = args.gpus
-    distributed = world > 1
+    # RTX_BENCH_FORCE_DIST=1 under torch.distributed.run with one rank walks the N>1 code (RCCL init, rings,
+    # all-reduce of the time) on a one-GPU box; the numbers it prints are not a bench line
+    distributed = world > 1 or os.environ.get("RTX_BENCH_FORCE_DIST") == "1"
     if distributed and world != n_gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (n_gpus, world))
     if not distributed and n_gpus != 1:
@@ -184,20 +190,43 @@ def main():
     else:
         import torch.distributed as dist
         stream = torch.cuda.current_stream()
-        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
+        if args.exchange == "rounds":
+            # frames in rounds of N, frame q*N+j assembled on rank j, one all-to-all per round; the N slab
+            # launches of a round go to F streams forked from / joined into torch's current stream, which the
+            # RCCL call is ordered after
+            pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2)
+            F = max(1, args.frames_in_flight)
+            rstreams = [torch.cuda.Stream() for _ in range(F)]
+            torch.cuda.synchronize()
+            submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,
+                                                  [pipe.slab(b, j).data_ptr() if rows else pipe.frames[b].data_ptr() for j in range(world)],
+                                                  [rstreams[j % F].cuda_stream for j in range(world)], stream.cuda_stream)
+                          for b in range(pipe.nbuf)]
 
-        def render(buf, r0, nrows, base):
-            # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
-            # RCCL transfers are ordered after.
-            ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
+            def render_round(q, b, nframes):
+                if rows:
+                    submitters[b](nframes)
 
-        elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
+            elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize)
+            last_frame = (q0 + -(-K // world) - 1) * world + (K - 1) % world
+            slab0 = pipe.slab(0, 0)
+        else:
+            pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
+
+            def render(buf, r0, nrows, base):
+                # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
+                # RCCL transfers are ordered after.
+                ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
+
+            elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
+            last_frame = K - 1
+            slab0 = pipe.slabs[0] if pipe.slabs is not None else None
         final = None
         if args.verify:
             # the last frame sits on its root; rank 0 reports, so ship the hash-relevant bytes there
-            last_root = pipe.root_of(K - 1)
+            last_root = pipe.root_of(last_frame)
             if rank == last_root:
-                buf = pipe.frame(K - 1)
+                buf = pipe.frame(last_frame)
                 if last_root != 0:
                     dist.send(buf, 0)
                 else:
@@ -210,8 +239,8 @@ def main():
         ctx.synchronize()
         ctx.timer_start()
         for _ in range(min(K, 50)):
-            tgt = pipe.slabs[0] if pipe.slabs is not None else pipe.frames[0]
-            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if pipe.slabs is not None else 0)
+            tgt = slab0 if slab0 is not None else pipe.frames[0]
+            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0)
         kernel_ms = ctx.timer_stop() / min(K, 50)
 
     rays_per_frame = (W - 1) * H
@@ -293,8 +322,11 @@ def main():
             "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
                                    % (args.config, W, H, ns, npl, args.mode, seed),
                        "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel,
-                       "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs + RCCL p2p gather; frame i assembled on rank %s"
-                                      % (n_gpus, "i %% N" if args.root == "rotate" else "0")},
+                       "parallelism": "1 GPU" if n_gpus == 1 else
+                                      ("rows sharded over %d GPUs; frames in rounds of N, frame i assembled on rank i %% N by one RCCL "
+                                       "all-to-all per round" % n_gpus) if args.exchange == "rounds" else
+                                      ("rows sharded over %d GPUs + RCCL p2p gather per frame; frame i assembled on rank %s"
+                                       % (n_gpus, "i %% N" if args.root == "rotate" else "0"))},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.what != "trace":

@@ -143,6 +143,15 @@ int rtx_render_rows(rtx_ctx* ctx, const rtx_params* params, int mode, size_t row
  * other streams: synchronise those streams first. */
 int rtx_submit_frames(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode, void* const* d_outs, void* const* streams);
 
+/* The row-sharded form of rtx_submit_frames (one rank's share of n consecutive frames in the multi-GPU loop,
+ * SURVEY.md 8(e)): rows [row0, row0+rows) of frame i are traced with params[i] into d_outs[i], whose first byte
+ * is row out_row_base, on streams[i].  If `after` (a hipStream_t) is not NULL the n slabs are ordered after
+ * everything queued on `after` so far, and `after` is made to wait for all of them (event fork/join inside the
+ * call), so that the caller can queue the exchange of the slabs on `after` right away.  No reference
+ * counterpart (the reference renders whole frames on one device, RayTracingManager.cu:122-135). */
+int rtx_submit_slabs(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode, size_t row0, size_t rows,
+                     void* const* d_outs, size_t out_row_base, void* const* streams, void* after);
+
 int rtx_synchronize(rtx_ctx* ctx);
 
 /* The context's device result buffer (m_deviceResultArray, RayTracingManager.h:45) and its size. */

@@ -60,6 +60,8 @@ _SIGNATURES = [
     ("rtx_render", C.c_int, [_P, C.POINTER(Params), C.c_int]),
     ("rtx_render_rows", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, C.c_uint]),
     ("rtx_submit_frames", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.POINTER(_P), C.POINTER(_P)]),
+    ("rtx_submit_slabs", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_P), C.c_size_t,
+                                   C.POINTER(_P), _P]),
     ("rtx_synchronize", C.c_int, [_P]),
     ("rtx_frame_device_ptr", _P, [_P]),
     ("rtx_frame_capacity", C.c_size_t, [_P]),
@@ -288,6 +290,30 @@ class Context:
             if rc != OK:
                 self._check(rc)
         submit._keep = keep
+        return submit
+
+    def submit_slabs(self, params_list, mode, row0, rows, d_outs, out_row_base, streams, after=None):
+        """rtx_submit_slabs: rows [row0, row0+rows) of len(params_list) frames with one call."""
+        n = len(params_list)
+        pa = (Params * n)(*params_list)
+        oa = (_P * n)(*d_outs)
+        sa = (_P * n)(*streams)
+        self._check(lib().rtx_submit_slabs(self._h, n, pa, mode, row0, rows, oa, out_row_base, sa, after))
+
+    def make_slab_submitter(self, params, mode, row0, rows, out_row_base, d_outs, streams, after):
+        """rtx_submit_slabs with pre-built argument arrays: rows [row0, row0+rows) of len(d_outs) frames, frame i
+        into d_outs[i] on streams[i], forked from / joined into the stream `after`.  Returns submit(count)."""
+        n = len(d_outs)
+        pa = (Params * n)(*([params] * n))
+        oa = (_P * n)(*d_outs)
+        sa = (_P * n)(*streams)
+        fn, h = lib().rtx_submit_slabs, self._h
+
+        def submit(count=n):
+            rc = fn(h, count, pa, mode, row0, rows, oa, out_row_base, sa, after)
+            if rc != OK:
+                self._check(rc)
+        submit._keep = (pa, oa, sa)
         return submit
 
     def synchronize(self):

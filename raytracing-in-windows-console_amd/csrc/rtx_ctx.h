@@ -54,6 +54,14 @@ struct rtx_ctx {
     };
     std::vector<CellScratch> cell_scratch;
 
+    // events of rtx_submit_slabs' fork/join: one for `after`, one per distinct render stream seen
+    hipEvent_t ev_fork = nullptr;
+    struct JoinEvent {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev = nullptr;
+    };
+    std::vector<JoinEvent> join_events;
+
     // pipelined Update (rtx_update_begin / rtx_update_end): two slots, each with its own frame, minimise
     // buffer, scan scratch and events; the copy of slot k's stream to the host runs on copy_stream while slot
     // k^1 is being traced

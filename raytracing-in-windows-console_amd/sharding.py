@@ -1,4 +1,7 @@
-"""Row sharding of a frame over ranks and its assembly on rank 0.
+"""Row sharding of a frame over ranks and its assembly on a root rank.
+
+Two frame loops over the same partition: RowShardedRounds (bench.py's default: frames in rounds of N with
+rotating roots, one all-to-all per round) and RowShardedFrames (one point-to-point gather per frame).
 
 The frame is row-major with row stride W*S (RayTracing.cu:238,457), so rows [r0, r1) are the contiguous
 byte range [r0*W*S, r1*W*S).  Rank g traces rows [H*g/N, H*(g+1)/N); the root posts one receive per
@@ -142,3 +145,100 @@ def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize):
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class RowShardedRounds:
+    """The N > 1 frame loop with one exchange per N frames.
+
+    Frames are taken in rounds of N = world consecutive frames; frame q*N + j is assembled on rank j.  In a
+    round every rank renders its row slab of each of the round's frames into one send buffer (slab j at byte
+    offset j*slab), and ONE all_to_all_single moves slab j of every rank to rank j, where the slabs land in
+    rank order = row order, i.e. as the complete frame.  Compared with a gather per frame this is N times
+    fewer, N times larger exchanges (the per-call cost of a collective is of the order of a whole frame's
+    trace), every directed xGMI link carries exactly one slab per round, and the N small slab launches of a
+    round can overlap on the device.  A round may hold fewer than N frames (the tail of a run): the absent
+    frames have zero-length splits.
+
+    Buffers: rings of `nbuf` send buffers (N slabs) and `nbuf` frames, so the exchange of a round overlaps
+    the rendering of the next.  `render_round(q, b, nframes)` must queue the rendering of this rank's rows of
+    frames q*N .. q*N+nframes-1 into `self.slab(b, j)`, ordered before whatever is queued next on the
+    current stream.  Device-agnostic (nccl = RCCL on GPUs; gloo in the CPU tests)."""
+
+    def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.W, self.H, self.S, self.nbuf = width, height, record_size, nbuf
+        self.bounds = row_bounds(height, world)
+        self.row0 = self.bounds[rank]
+        self.rows = self.bounds[rank + 1] - self.bounds[rank]
+        self.slab_len = record_size * width * self.rows
+        self.all_slab_len = [slab_bytes(self.bounds, g, width, record_size) for g in range(world)]
+        self.frame_len = record_size * width * height
+        self.send = [torch.zeros(world * self.slab_len, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        # 20*W*H bytes each: the reference's frame size whatever the mode (PrintMachine.cpp:140)
+        self.frames = [torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.nothing = torch.zeros(0, dtype=torch.uint8, device=device)
+        self.pending = [None] * nbuf
+        self.where = {}   # frame number -> frame ring index (frames rooted here)
+
+    def root_of(self, i):
+        return i % self.world
+
+    def slab(self, b, j):
+        return self.send[b][j * self.slab_len:(j + 1) * self.slab_len]
+
+    def round(self, q, nframes, render_round):
+        b = q % self.nbuf
+        if self.pending[b] is not None:   # the exchange that last read send[b] and wrote frames[b]
+            self.pending[b].wait()
+            self.pending[b] = None
+        render_round(q, b, nframes)
+        ins = [self.slab_len if j < nframes else 0 for j in range(self.world)]
+        if self.rank < nframes:
+            out, outs = self.frames[b][:self.frame_len], self.all_slab_len
+            self.where[q * self.world + self.rank] = b
+        else:
+            out, outs = self.nothing, [0] * self.world
+        self.pending[b] = self.dist.all_to_all_single(out, self.send[b][:nframes * self.slab_len], outs, ins, async_op=True)
+
+    def run(self, first_round, count, render_round):
+        """`count` frames starting at round `first_round`; returns the next round number."""
+        q = first_round
+        while count > 0:
+            n = min(self.world, count)
+            self.round(q, n, render_round)
+            count -= n
+            q += 1
+        return q
+
+    def drain(self):
+        for b in range(self.nbuf):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def frame(self, i):
+        """On the root of frame i: the buffer it was assembled in (valid after drain() and until nbuf more
+        rounds have passed)."""
+        return self.frames[self.where[i]]
+
+
+def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize):
+    """bench.py's timing contract for RowShardedRounds: warm-up, then exactly `steps` frames between
+    barrier + synchronize on both sides; returns (MAX over ranks of the elapsed seconds, first timed round)."""
+    import time
+    q = pipe.run(0, pipe.world, render_round)   # communicator set-up: one full round, neither timed nor counted
+    pipe.drain()
+    q = pipe.run(q, warmup, render_round)
+    pipe.drain()
+    dist.barrier()
+    synchronize()
+    t0 = time.perf_counter()
+    q0 = q
+    pipe.run(q, steps, render_round)
+    pipe.drain()
+    synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item()), q0

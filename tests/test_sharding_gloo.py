@@ -122,3 +122,65 @@ def test_bench_frame_pipeline_over_gloo(tmp_path, world, rotate):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_pipeline_worker, args=(world, _free_port(), rotate, out), nprocs=world, join=True)
     assert int(np.load(out)[0]) == 1
+
+
+def _frame_params(R, W, H, i):
+    # a different camera per frame number, so that a slab delivered to the wrong frame or root shows
+    return R.camera_params(W, H, pos=(0.05 * i, 0.0, 0.0), rot=(0.0, np.pi + 0.01 * i, 0.0))
+
+
+def _rounds_worker(rank, world, port, steps, warmup, out_path):
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (here, os.path.dirname(here)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import importlib
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
+    R = U.pkg()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        _, sph, pl = R.config_inputs("C1")
+        W, H = R.CONFIGS["C1"][0], R.CONFIGS["C1"][1]
+        mode, S = O.RGB_ASCII, 20
+        sc = O.Scene.from_arrays(sph, pl)
+        pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cpu", nbuf=2)
+        rendered = []
+
+        def render_round(q, b, nframes):
+            # the oracle stands in for rtx_submit_slabs: this rank's rows of frames q*N .. q*N+nframes-1
+            for j in range(nframes):
+                i = q * world + j
+                full = O.render(U.oracle_params(_frame_params(R, W, H, i)), sc, mode, row0=pipe.row0, rows=pipe.rows)
+                pipe.slab(b, j).numpy()[:] = full[pipe.row0 * W * S:(pipe.row0 + pipe.rows) * W * S]
+                rendered.append(i)
+
+        elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, steps=steps, warmup=warmup, device="cpu",
+                                            synchronize=lambda: None)
+        assert elapsed > 0 and len(rendered) == world + warmup + steps
+        ok = 1
+        # the frames of the last round (still in the ring), wherever they were assembled
+        rounds = -(-steps // world)
+        last_q = q0 + rounds - 1
+        n_last = steps - (rounds - 1) * world
+        for j in range(n_last):
+            i = last_q * world + j
+            assert pipe.root_of(i) == j
+            if j == rank:
+                want = O.render(U.oracle_params(_frame_params(R, W, H, i)), sc, mode)
+                ok &= int(np.array_equal(pipe.frame(i).numpy(), want))
+        t = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            np.save(out_path, np.array([int(t.item())]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,steps,warmup", [(2, 6, 2), (2, 5, 1), (3, 7, 2), (3, 6, 0)])
+def test_bench_round_pipeline_over_gloo(tmp_path, world, steps, warmup):
+    """The loop bench.py runs by default for --gpus N (RowShardedRounds + timed_rounds: one all-to-all per N
+    frames, frame q*N+j assembled on rank j) over gloo with CPU tensors, full and partial last rounds, every
+    frame with its own camera."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, out), nprocs=world, join=True)
+    assert int(np.load(out)[0]) == 1

@@ -69,9 +69,11 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the assembled frame against the golden hash")
     ap.add_argument("--root", default="rotate", choices=["rotate", "fixed"],
                     help="N>1: frame i is assembled on rank i %% N (rotate) or always on rank 0 (fixed)")
-    ap.add_argument("--exchange", default="rounds", choices=["rounds", "p2p"],
-                    help="N>1: rounds = frames in rounds of N with rotating roots and one RCCL all-to-all per round "
-                         "(default); p2p = one point-to-point gather per frame (see --root)")
+    ap.add_argument("--exchange", default="compact", choices=["compact", "rounds", "p2p"],
+                    help="N>1: compact (default) = frames in rounds of M*N with rotating roots, one RCCL all-to-all per "
+                         "round, slabs as 4-byte pixel words expanded into records on the root; rounds = the same with "
+                         "the slabs as records (M=1); p2p = one point-to-point gather per frame (see --root)")
+    ap.add_argument("--frames-per-root", type=int, default=0, help="N>1, --exchange compact: M (0 = 8/4/4 for 2/4/8 GPUs)")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
@@ -190,17 +192,45 @@ def main():
     else:
         import torch.distributed as dist
         stream = torch.cuda.current_stream()
-        if args.exchange == "rounds":
-            # frames in rounds of N, frame q*N+j assembled on rank j, one all-to-all per round; the N slab
-            # launches of a round go to F streams forked from / joined into torch's current stream, which the
-            # RCCL call is ordered after
-            pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2)
+        if args.exchange in ("compact", "rounds"):
+            # Frames in rounds of M*N, frame m*N+j of a round assembled on rank j, ONE all-to-all per round.  The
+            # slab launches of a round go to F streams forked from / joined into torch's current stream (inside
+            # rtx_submit_slabs), which the RCCL call is ordered after.  "compact": the slabs travel as 4-byte
+            # pixel words and the root expands them into records on a side stream once the exchange is done.
+            compact = args.exchange == "compact"
+            M = 1 if not compact else (args.frames_per_root or {2: 8, 4: 4, 8: 4}.get(world, max(1, 16 // world)))
+            post = torch.cuda.Stream()
+            expanders = {}
+
+            class _After:
+                def __init__(self, ev):
+                    self.ev = ev
+
+                def wait(self):
+                    torch.cuda.current_stream().wait_event(self.ev)
+
+            def finish(q, b, work, mine):
+                with torch.cuda.stream(post):
+                    work.wait()   # orders `post` (only) after the exchange
+                    for m, segs in mine:
+                        key = (b, m, len(mine))
+                        if key not in expanders:
+                            expanders[key] = ctx.make_expander(mode, pipe.recv[b].data_ptr(), pipe.frames[b][m].data_ptr(), segs, post.cuda_stream)
+                        expanders[key]()
+                    ev = torch.cuda.Event()
+                    ev.record(post)
+                return _After(ev)
+
+            pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, frames_per_root=M,
+                                             pixel_bytes=4 if compact else None, finish=finish if compact else None)
             F = max(1, args.frames_in_flight)
             rstreams = [torch.cuda.Stream() for _ in range(F)]
             torch.cuda.synchronize()
+            RF = pipe.round_frames
             submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,
-                                                  [pipe.slab(b, j).data_ptr() if rows else pipe.frames[b].data_ptr() for j in range(world)],
-                                                  [rstreams[j % F].cuda_stream for j in range(world)], stream.cuda_stream)
+                                                  [pipe.unit(b, f).data_ptr() if rows else pipe.frames[b][0].data_ptr() for f in range(RF)],
+                                                  [rstreams[f % F].cuda_stream for f in range(RF)], stream.cuda_stream,
+                                                  flags=R.RENDER_COMPACT if compact else 0)
                           for b in range(pipe.nbuf)]
 
             def render_round(q, b, nframes):
@@ -208,8 +238,12 @@ def main():
                     submitters[b](nframes)
 
             elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize)
-            last_frame = (q0 + -(-K // world) - 1) * world + (K - 1) % world
-            slab0 = pipe.slab(0, 0)
+            n_rounds = -(-K // RF)
+            last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
+            slab0 = pipe.unit(0, 0)
+            exchange_note = ("frames in rounds of %d (M=%d per root), frame i of a round assembled on rank i %% N by one RCCL all-to-all per round; "
+                             % (RF, M)) + ("slabs travel as 4-byte pixel words, the root expands them into records (rtx_expand)" if compact
+                                           else "slabs travel as records")
         else:
             pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
 
@@ -221,6 +255,7 @@ def main():
             elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
             last_frame = K - 1
             slab0 = pipe.slabs[0] if pipe.slabs is not None else None
+            exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
         final = None
         if args.verify:
             # the last frame sits on its root; rank 0 reports, so ship the hash-relevant bytes there
@@ -240,7 +275,8 @@ def main():
         ctx.timer_start()
         for _ in range(min(K, 50)):
             tgt = slab0 if slab0 is not None else pipe.frames[0]
-            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0)
+            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0,
+                            flags=R.RENDER_COMPACT if args.exchange == "compact" else 0)
         kernel_ms = ctx.timer_stop() / min(K, 50)
 
     rays_per_frame = (W - 1) * H
@@ -262,7 +298,8 @@ def main():
             verified = bool(g) and O.fnv1a64(final) == g.get("frame_fnv1a64")
 
         my_rows = rows
-        bytes_alg = algorithmic_bytes(W, H, S, ns, npl, my_rows)
+        # the trace kernel of a rank writes S bytes per pixel, or 4 when the slabs travel as pixel words
+        bytes_alg = algorithmic_bytes(W, H, 4 if (distributed and args.exchange == "compact") else S, ns, npl, my_rows)
         achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters of the committed profile of this same kernel
         # (profiles/traffic.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none.
@@ -322,11 +359,7 @@ def main():
             "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
                                    % (args.config, W, H, ns, npl, args.mode, seed),
                        "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel,
-                       "parallelism": "1 GPU" if n_gpus == 1 else
-                                      ("rows sharded over %d GPUs; frames in rounds of N, frame i assembled on rank i %% N by one RCCL "
-                                       "all-to-all per round" % n_gpus) if args.exchange == "rounds" else
-                                      ("rows sharded over %d GPUs + RCCL p2p gather per frame; frame i assembled on rank %s"
-                                       % (n_gpus, "i %% N" if args.root == "rotate" else "0"))},
+                       "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs; %s" % (n_gpus, exchange_note)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.what != "trace":

@@ -88,8 +88,23 @@ enum rtx_render_flags {
     /* 8-bit modes use only the first 12*W*H bytes of the 20*W*H frame (RayTracing.cu:238);
      * with this flag the call also zero-fills bytes [12*W*H, 20*W*H) of a full-frame buffer,
      * as the reference's per-frame cudaMemset leaves them (RayTracingManager.cu:86,161-165). */
-    RTX_RENDER_ZERO_TAIL = 1
+    RTX_RENDER_ZERO_TAIL = 1,
+    /* The output is one 4-byte pixel word per pixel (W*rows words, same row addressing as the records, caller's
+     * buffer only) instead of the S-byte record: byte 0..2 = the record's colour values (r, g, b; or the
+     * xterm-256 index in byte 0 for the 8-bit modes), byte 3 = the glyph; 0 = pixel without a visible hit;
+     * 0xffffffff = column W-1.  rtx_expand turns the words into the very records rtx_render_rows would have
+     * written.  For the row-sharded multi-GPU loop: a rank ships 4 instead of 20 bytes per pixel over xGMI and
+     * the GPU that assembles the frame writes the records.  No reference counterpart.  Not with RTX_SDL. */
+    RTX_RENDER_COMPACT = 2
 };
+
+/* One run of pixels for rtx_expand: n_pixels words starting at word src_pixel of the compact buffer become
+ * the records starting at record dst_pixel of the output buffer. */
+typedef struct rtx_segment {
+    uint64_t src_pixel;
+    uint64_t dst_pixel;
+    uint64_t n_pixels;
+} rtx_segment;
 
 /* ---- context: RayTracingManager::RayTracingManager / ~RayTracingManager (RayTracingManager.cu:53-74).
  * Owns the device params block, the 20*max_w*max_h device result buffer (PrintMachine::GetMaxSize(),
@@ -147,10 +162,18 @@ int rtx_submit_frames(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode
  * SURVEY.md 8(e)): rows [row0, row0+rows) of frame i are traced with params[i] into d_outs[i], whose first byte
  * is row out_row_base, on streams[i].  If `after` (a hipStream_t) is not NULL the n slabs are ordered after
  * everything queued on `after` so far, and `after` is made to wait for all of them (event fork/join inside the
- * call), so that the caller can queue the exchange of the slabs on `after` right away.  No reference
+ * call), so that the caller can queue the exchange of the slabs on `after` right away.  `flags` as for
+ * rtx_render_rows (RTX_RENDER_COMPACT: d_outs[i] receives pixel words).  No reference
  * counterpart (the reference renders whole frames on one device, RayTracingManager.cu:122-135). */
 int rtx_submit_slabs(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode, size_t row0, size_t rows,
-                     void* const* d_outs, size_t out_row_base, void* const* streams, void* after);
+                     void* const* d_outs, size_t out_row_base, void* const* streams, void* after, unsigned flags);
+
+/* Compact pixel words (RTX_RENDER_COMPACT) -> records of `mode` (12 bytes per pixel for the 8-bit modes, 20 for
+ * the RGB ones; the record encoders of RayTracing.cu:206-252, 287-332, 370-472, 507-609, 645-751), for n_segments
+ * runs of pixels, on `stream` (NULL = the context's).  d_compact and d_out are device memory of the caller,
+ * 4-byte aligned (16-byte aligned destinations take the fast path).  Asynchronous. */
+int rtx_expand(rtx_ctx* ctx, int mode, const void* d_compact, void* d_out, const rtx_segment* segments,
+               size_t n_segments, void* stream);
 
 int rtx_synchronize(rtx_ctx* ctx);
 

@@ -26,12 +26,18 @@ OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_D
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
 OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL = 1, 2, 3, 4
 RENDER_ZERO_TAIL = 1
+RENDER_COMPACT = 2
 
 
 class RtxError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("rtx status %d: %s" % (status, message))
         self.status = status
+
+
+class Segment(C.Structure):
+    """struct rtx_segment: one run of pixels for rtx_expand."""
+    _fields_ = [("src_pixel", C.c_uint64), ("dst_pixel", C.c_uint64), ("n_pixels", C.c_uint64)]
 
 
 class Params(C.Structure):
@@ -61,7 +67,8 @@ _SIGNATURES = [
     ("rtx_render_rows", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, _P, C.c_size_t, _P, C.c_uint]),
     ("rtx_submit_frames", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     ("rtx_submit_slabs", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_P), C.c_size_t,
-                                   C.POINTER(_P), _P]),
+                                   C.POINTER(_P), _P, C.c_uint]),
+    ("rtx_expand", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, _P]),
     ("rtx_synchronize", C.c_int, [_P]),
     ("rtx_frame_device_ptr", _P, [_P]),
     ("rtx_frame_capacity", C.c_size_t, [_P]),
@@ -292,15 +299,15 @@ class Context:
         submit._keep = keep
         return submit
 
-    def submit_slabs(self, params_list, mode, row0, rows, d_outs, out_row_base, streams, after=None):
+    def submit_slabs(self, params_list, mode, row0, rows, d_outs, out_row_base, streams, after=None, flags=0):
         """rtx_submit_slabs: rows [row0, row0+rows) of len(params_list) frames with one call."""
         n = len(params_list)
         pa = (Params * n)(*params_list)
         oa = (_P * n)(*d_outs)
         sa = (_P * n)(*streams)
-        self._check(lib().rtx_submit_slabs(self._h, n, pa, mode, row0, rows, oa, out_row_base, sa, after))
+        self._check(lib().rtx_submit_slabs(self._h, n, pa, mode, row0, rows, oa, out_row_base, sa, after, flags))
 
-    def make_slab_submitter(self, params, mode, row0, rows, out_row_base, d_outs, streams, after):
+    def make_slab_submitter(self, params, mode, row0, rows, out_row_base, d_outs, streams, after, flags=0):
         """rtx_submit_slabs with pre-built argument arrays: rows [row0, row0+rows) of len(d_outs) frames, frame i
         into d_outs[i] on streams[i], forked from / joined into the stream `after`.  Returns submit(count)."""
         n = len(d_outs)
@@ -310,11 +317,30 @@ class Context:
         fn, h = lib().rtx_submit_slabs, self._h
 
         def submit(count=n):
-            rc = fn(h, count, pa, mode, row0, rows, oa, out_row_base, sa, after)
+            rc = fn(h, count, pa, mode, row0, rows, oa, out_row_base, sa, after, flags)
             if rc != OK:
                 self._check(rc)
         submit._keep = (pa, oa, sa)
         return submit
+
+    def expand(self, mode, d_compact, d_out, segments, stream=None):
+        """rtx_expand: compact pixel words -> records; segments = [(src_pixel, dst_pixel, n_pixels), ...]."""
+        n = len(segments)
+        sa = (Segment * n)(*[Segment(*g) for g in segments])
+        self._check(lib().rtx_expand(self._h, mode, d_compact, d_out, sa, n, stream))
+
+    def make_expander(self, mode, d_compact, d_out, segments, stream=None):
+        """rtx_expand with a pre-built segment array: returns a callable."""
+        n = len(segments)
+        sa = (Segment * n)(*[Segment(*g) for g in segments])
+        fn, h = lib().rtx_expand, self._h
+
+        def expand():
+            rc = fn(h, mode, d_compact, d_out, sa, n, stream)
+            if rc != OK:
+                self._check(rc)
+        expand._keep = sa
+        return expand
 
     def synchronize(self):
         self._check(lib().rtx_synchronize(self._h))

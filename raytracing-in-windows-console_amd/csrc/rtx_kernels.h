@@ -46,13 +46,29 @@ struct KArgs {
     uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
     uint32_t cells_x;
     uint8_t* out;             // records of row out_row_base start here
+    uint32_t compact;         // RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record
 #ifdef RTX_ABLATE
     uint32_t ablate;          // experiment builds only (make ablate): bit mask of stages to skip
     unsigned long long* stamps; // experiment builds only: 16 timestamps per workgroup (s_memtime), or nullptr
 #endif
 };
 
+// Arguments of rtx_expand_words (compact pixel words -> records), by value.
+constexpr int kMaxExpandSeg = 16;
+constexpr int kExpandPixels = 1024;             // pixels per workgroup
+struct ExpandArgs {
+    const uint32_t* src;                    // compact words
+    uint8_t* dst;                           // records
+    uint32_t nseg;
+    uint32_t aligned16;                     // every destination segment starts on a 16-byte boundary
+    uint32_t first_block[kMaxExpandSeg + 1]; // workgroups [first_block[k], first_block[k+1]) expand segment k
+    uint32_t npix[kMaxExpandSeg];
+    uint64_t src_px[kMaxExpandSeg];         // first pixel of the segment in src / dst
+    uint64_t dst_px[kMaxExpandSeg];
+};
+
 extern "C" {
+int rtx_k_launch_expand(const ExpandArgs* e, int mode, unsigned blocks, void* stream);
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);

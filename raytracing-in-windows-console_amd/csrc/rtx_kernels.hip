@@ -179,6 +179,80 @@ struct Best {
     uint32_t k; // local sphere index, or 0xffffffff
 };
 
+// What a visible pixel's record is made of: the colour bytes (r, g, b; or the xterm-256 index in c0 for the
+// 8-bit modes) and the glyph.  RTX_RENDER_COMPACT stores exactly these 4 bytes per pixel and rtx_expand
+// builds the record from them later (on the GPU that assembles the frame), so both go through record_words.
+struct Fields {
+    uint32_t c0, c1, c2, glyph;
+};
+
+template <int MODE>
+__device__ __forceinline__ Fields pixel_fields(const KArgs& a, const uint8_t* s_ramp, V3 normal, V3 colour, float shadingValue)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    Fields f;
+    if (kRgb) {
+        if (MODE == RTX_K_RGB_NORMALS) {
+            f.c0 = u8_sat(normal.x * 255.0f);
+            f.c1 = u8_sat(normal.y * 255.0f);
+            f.c2 = u8_sat(normal.z * 255.0f);
+        } else {
+            f.c0 = u8_sat(colour.x);
+            f.c1 = u8_sat(colour.y);
+            f.c2 = u8_sat(colour.z);
+        }
+        f.glyph = (MODE == RTX_K_RGB_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
+    } else {
+        f.c0 = ansi256_from_rgb(u8_sat(colour.x), u8_sat(colour.y), u8_sat(colour.z), a.grey);
+        f.c1 = f.c2 = 0u;
+        f.glyph = (MODE == RTX_K_BIT_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
+    }
+    return f;
+}
+
+// The record (5 dwords RGB, 3 dwords 8-bit) of one pixel, App. B of SURVEY.md byte for byte.
+template <int MODE>
+__device__ __forceinline__ void record_words(bool visible, const Fields& f, const uint32_t* s_digits, uint32_t* w)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    const uint32_t ESC_BR = 0x1bu | (0x5bu << 8); // ESC [
+    if (kRgb) {
+        if (visible) {
+            const uint32_t dr = s_digits[f.c0], dg = s_digits[f.c1], db = s_digits[f.c2];
+            const uint32_t kind = (MODE == RTX_K_RGB_ASCII) ? '3' : '4';
+            w[0] = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
+            w[1] = (uint32_t)';' | ((uint32_t)'2' << 8) | ((uint32_t)';' << 16) | ((dr & 255u) << 24);
+            w[2] = (dr >> 8) | ((uint32_t)';' << 16) | ((dg & 255u) << 24);
+            w[3] = (dg >> 8) | ((uint32_t)';' << 16) | ((db & 255u) << 24);
+            w[4] = (db >> 8) | ((uint32_t)'m' << 16) | (f.glyph << 24);
+        } else {
+            // ESC [ 4 8 ; 2 ; \0 \0 0 ; \0 \0 0 ; \0 \0 0 m ' '
+            w[0] = ESC_BR | ((uint32_t)'4' << 16) | ((uint32_t)'8' << 24);
+            w[1] = (uint32_t)';' | ((uint32_t)'2' << 8) | ((uint32_t)';' << 16);
+            w[2] = ((uint32_t)'0' << 8) | ((uint32_t)';' << 16);
+            w[3] = ((uint32_t)'0' << 8) | ((uint32_t)';' << 16);
+            w[4] = ((uint32_t)'0' << 8) | ((uint32_t)'m' << 16) | ((uint32_t)' ' << 24);
+        }
+    } else {
+        if (visible) {
+            const uint32_t d = s_digits[f.c0];
+            const uint32_t kind = (MODE == RTX_K_BIT_ASCII) ? '3' : '4';
+            w[0] = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
+            w[1] = (uint32_t)';' | ((uint32_t)'5' << 8) | ((uint32_t)';' << 16) | ((d & 255u) << 24);
+            w[2] = (d >> 8) | ((uint32_t)'m' << 16) | (f.glyph << 24);
+        } else {
+            // ESC [ 4 8 ; 5 ; \0 1 6 m ' '
+            w[0] = ESC_BR | ((uint32_t)'4' << 16) | ((uint32_t)'8' << 24);
+            w[1] = (uint32_t)';' | ((uint32_t)'5' << 8) | ((uint32_t)';' << 16);
+            w[2] = (uint32_t)'1' | ((uint32_t)'6' << 8) | ((uint32_t)'m' << 16) | ((uint32_t)' ' << 24);
+        }
+    }
+}
+
+// Compact pixel word (RTX_RENDER_COMPACT): c0 | c1<<8 | c2<<16 | glyph<<24 for a visible pixel (the glyph byte
+// is never 0), 0 for a pixel beyond the far plane or without a hit, 0xffffffff for the untraced column W-1.
+constexpr uint32_t kCompactMiss = 0u, kCompactNewline = 0xffffffffu;
+
 template <int MODE>
 __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const uint32_t* s_digits, const uint8_t* s_ramp, bool in_frame, bool is_newline_col,
                                                  uint32_t row, uint32_t col, float distance, V3 normal, V3 colour, float shadingValue)
@@ -186,6 +260,23 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
     constexpr uint32_t S = kRgb ? 20u : 12u;
     if (!in_frame) {
+        return;
+    }
+    const bool visible = distance <= cam.far; // RayTracing.cu:207,288,371,508,646
+#ifdef RTX_NO_COMPACT // A/B experiment builds only (make variant)
+    if (false) {
+#else
+    if (a.compact) {
+#endif
+        uint32_t word = kCompactNewline;
+        if (!is_newline_col) {
+            word = kCompactMiss;
+            if (visible) {
+                const Fields f = pixel_fields<MODE>(a, s_ramp, normal, colour, shadingValue);
+                word = f.c0 | (f.c1 << 8) | (f.c2 << 16) | (f.glyph << 24);
+            }
+        }
+        reinterpret_cast<uint32_t*>(a.out)[(size_t)(row - a.out_row_base) * a.W + col] = word;
         return;
     }
     uint32_t* dst = reinterpret_cast<uint32_t*>(a.out + ((size_t)(row - a.out_row_base) * a.W + col) * S);
@@ -197,61 +288,15 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
         }
         return;
     }
-    const bool visible = distance <= cam.far; // RayTracing.cu:207,288,371,508,646
-    const uint32_t ESC_BR = 0x1bu | (0x5bu << 8); // ESC [
-    if (kRgb) {
-        uint32_t w0, w1, w2, w3, w4;
-        if (visible) {
-            uint32_t r, g, b;
-            if (MODE == RTX_K_RGB_NORMALS) {
-                r = u8_sat(normal.x * 255.0f);
-                g = u8_sat(normal.y * 255.0f);
-                b = u8_sat(normal.z * 255.0f);
-            } else {
-                r = u8_sat(colour.x);
-                g = u8_sat(colour.y);
-                b = u8_sat(colour.z);
-            }
-            const uint32_t dr = s_digits[r], dg = s_digits[g], db = s_digits[b];
-            const uint32_t kind = (MODE == RTX_K_RGB_ASCII) ? '3' : '4';
-            const uint32_t glyph = (MODE == RTX_K_RGB_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
-            w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
-            w1 = (uint32_t)';' | ((uint32_t)'2' << 8) | ((uint32_t)';' << 16) | ((dr & 255u) << 24);
-            w2 = (dr >> 8) | ((uint32_t)';' << 16) | ((dg & 255u) << 24);
-            w3 = (dg >> 8) | ((uint32_t)';' << 16) | ((db & 255u) << 24);
-            w4 = (db >> 8) | ((uint32_t)'m' << 16) | (glyph << 24);
-        } else {
-            // ESC [ 4 8 ; 2 ; \0 \0 0 ; \0 \0 0 ; \0 \0 0 m ' '
-            w0 = ESC_BR | ((uint32_t)'4' << 16) | ((uint32_t)'8' << 24);
-            w1 = (uint32_t)';' | ((uint32_t)'2' << 8) | ((uint32_t)';' << 16);
-            w2 = ((uint32_t)'0' << 8) | ((uint32_t)';' << 16);
-            w3 = ((uint32_t)'0' << 8) | ((uint32_t)';' << 16);
-            w4 = ((uint32_t)'0' << 8) | ((uint32_t)'m' << 16) | ((uint32_t)' ' << 24);
-        }
-        dst[0] = w0;
-        dst[1] = w1;
-        dst[2] = w2;
-        dst[3] = w3;
-        dst[4] = w4;
-    } else {
-        uint32_t w0, w1, w2;
-        if (visible) {
-            const uint32_t index = ansi256_from_rgb(u8_sat(colour.x), u8_sat(colour.y), u8_sat(colour.z), a.grey);
-            const uint32_t d = s_digits[index];
-            const uint32_t kind = (MODE == RTX_K_BIT_ASCII) ? '3' : '4';
-            const uint32_t glyph = (MODE == RTX_K_BIT_ASCII) ? (uint32_t)s_ramp[ramp_index(shadingValue)] : (uint32_t)' ';
-            w0 = ESC_BR | (kind << 16) | ((uint32_t)'8' << 24);
-            w1 = (uint32_t)';' | ((uint32_t)'5' << 8) | ((uint32_t)';' << 16) | ((d & 255u) << 24);
-            w2 = (d >> 8) | ((uint32_t)'m' << 16) | (glyph << 24);
-        } else {
-            // ESC [ 4 8 ; 5 ; \0 1 6 m ' '
-            w0 = ESC_BR | ((uint32_t)'4' << 16) | ((uint32_t)'8' << 24);
-            w1 = (uint32_t)';' | ((uint32_t)'5' << 8) | ((uint32_t)';' << 16);
-            w2 = (uint32_t)'1' | ((uint32_t)'6' << 8) | ((uint32_t)'m' << 16) | ((uint32_t)' ' << 24);
-        }
-        dst[0] = w0;
-        dst[1] = w1;
-        dst[2] = w2;
+    uint32_t w[5];
+    Fields f = {0u, 0u, 0u, 0u};
+    if (visible) {
+        f = pixel_fields<MODE>(a, s_ramp, normal, colour, shadingValue);
+    }
+    record_words<MODE>(visible, f, s_digits, w);
+#pragma unroll
+    for (uint32_t i = 0; i < S / 4u; i++) {
+        dst[i] = w[i];
     }
 }
 
@@ -777,7 +822,95 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
     }
 }
 
+// rtx_expand: compact pixel words -> records, for up to kMaxExpandSeg segments (a segment = a run of pixels that
+// is contiguous in both buffers: one rank's rows of one frame).  Pure streaming: 4 bytes read, S written per pixel.
+// A workgroup takes kExpandPixels consecutive pixels of one segment, 256 at a time; each wave transposes the
+// records of its 64 pixels through its own piece of LDS (pixel p at dword p*S/4, odd stride: conflict-free), so
+// that its 64*S bytes leave as whole 16-byte stores in address order -- wave-local, no workgroup barrier.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void rtx_expand_words(const ExpandArgs e)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    constexpr uint32_t SW = kRgb ? 5u : 3u; // dwords per record
+    __shared__ uint32_t s_digits[256];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rec[kThreads * SW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    s_digits[tid] = kDigits.v[tid];
+    uint32_t k = 0;
+    while (k + 1u < e.nseg && blockIdx.x >= e.first_block[k + 1u]) {
+        k++;
+    }
+    const uint32_t npix = e.npix[k];
+    const uint32_t* src = e.src + e.src_px[k];
+    uint32_t* dst_seg = reinterpret_cast<uint32_t*>(e.dst) + e.dst_px[k] * SW;
+    const uint32_t base = (blockIdx.x - e.first_block[k]) * (uint32_t)kExpandPixels;
+    uint32_t* s_wave = s_rec + wave * 64u * SW;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t c = 0; c < (uint32_t)kExpandPixels; c += (uint32_t)kThreads) {
+        const uint32_t w0 = base + c + wave * 64u; // first pixel of this wave's 64
+        if (w0 >= npix) {
+            break;
+        }
+        const uint32_t p = w0 + lane;
+        const bool valid = p < npix;
+        const uint32_t word = valid ? src[p] : kCompactNewline;
+        uint32_t w[SW];
+        if (word == kCompactNewline) {
+#pragma unroll
+            for (uint32_t i = 0; i < SW; i++) {
+                w[i] = 0u;
+            }
+        } else {
+            Fields f;
+            f.c0 = word & 255u;
+            f.c1 = (word >> 8) & 255u;
+            f.c2 = (word >> 16) & 255u;
+            f.glyph = word >> 24;
+            record_words<MODE>(word != kCompactMiss, f, s_digits, w);
+        }
+        uint32_t* dst = dst_seg + (size_t)w0 * SW;
+        if (e.aligned16 && w0 + 64u <= npix) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the previous round's reads of s_wave are done
+#pragma unroll
+            for (uint32_t i = 0; i < SW; i++) {
+                s_wave[lane * SW + i] = w[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // wave-local: LDS is in order within a wave
+            const uint4* s4 = reinterpret_cast<const uint4*>(s_wave);
+            uint4* d4 = reinterpret_cast<uint4*>(dst);
+            constexpr uint32_t n4 = 16u * SW; // 16-byte pieces of the wave's 64 records: 80 or 48
+            if (lane < n4) {
+                d4[lane] = s4[lane];
+            }
+            if (64u + lane < n4) {
+                d4[64u + lane] = s4[64u + lane];
+            }
+        } else if (valid) {
+#pragma unroll
+            for (uint32_t i = 0; i < SW; i++) {
+                dst[(size_t)lane * SW + i] = w[i];
+            }
+        }
+    }
+}
+
 } // namespace rtx
+
+extern "C" int rtx_k_launch_expand(const ExpandArgs* e, int mode, unsigned blocks, void* stream_v)
+{
+    using namespace rtx;
+    hipStream_t stream = (hipStream_t)stream_v;
+    switch (mode) {
+    case RTX_K_BIT_ASCII: hipLaunchKernelGGL((rtx_expand_words<RTX_K_BIT_ASCII>), dim3(blocks), dim3(kThreads), 0, stream, *e); break;
+    case RTX_K_BIT_PIXEL: hipLaunchKernelGGL((rtx_expand_words<RTX_K_BIT_PIXEL>), dim3(blocks), dim3(kThreads), 0, stream, *e); break;
+    case RTX_K_RGB_ASCII: hipLaunchKernelGGL((rtx_expand_words<RTX_K_RGB_ASCII>), dim3(blocks), dim3(kThreads), 0, stream, *e); break;
+    case RTX_K_RGB_PIXEL: hipLaunchKernelGGL((rtx_expand_words<RTX_K_RGB_PIXEL>), dim3(blocks), dim3(kThreads), 0, stream, *e); break;
+    case RTX_K_RGB_NORMALS: hipLaunchKernelGGL((rtx_expand_words<RTX_K_RGB_NORMALS>), dim3(blocks), dim3(kThreads), 0, stream, *e); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
 
 extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream_v, int* hip_error)
 {

@@ -148,63 +148,130 @@ def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize):
 
 
 class RowShardedRounds:
-    """The N > 1 frame loop with one exchange per N frames.
+    """The N > 1 frame loop with one exchange per round of M*N frames.
 
-    Frames are taken in rounds of N = world consecutive frames; frame q*N + j is assembled on rank j.  In a
-    round every rank renders its row slab of each of the round's frames into one send buffer (slab j at byte
-    offset j*slab), and ONE all_to_all_single moves slab j of every rank to rank j, where the slabs land in
-    rank order = row order, i.e. as the complete frame.  Compared with a gather per frame this is N times
-    fewer, N times larger exchanges (the per-call cost of a collective is of the order of a whole frame's
-    trace), every directed xGMI link carries exactly one slab per round, and the N small slab launches of a
-    round can overlap on the device.  A round may hold fewer than N frames (the tail of a run): the absent
-    frames have zero-length splits.
+    Frame f of a round (f = m*N + j, m < M) is assembled on rank j: consecutive frames rotate over the roots
+    and every root receives M frames per round.  In a round every rank renders its row slab of each of the
+    round's frames into one send buffer (the slab of frame f at unit (j*M + m), so that everything bound for
+    rank j is contiguous) and ONE all_to_all_single moves it: per round each directed xGMI link carries M
+    slabs, and the per-call cost of the collective (of the order of a whole frame's trace) is paid once per
+    M*N frames -- fewer, larger collectives.  A round may hold fewer frames (the tail of a run): the absent
+    frames shrink the splits.
 
-    Buffers: rings of `nbuf` send buffers (N slabs) and `nbuf` frames, so the exchange of a round overlaps
-    the rendering of the next.  `render_round(q, b, nframes)` must queue the rendering of this rank's rows of
-    frames q*N .. q*N+nframes-1 into `self.slab(b, j)`, ordered before whatever is queued next on the
-    current stream.  Device-agnostic (nccl = RCCL on GPUs; gloo in the CPU tests)."""
+    Two forms of the slabs:
+      * records (`pixel_bytes` = S, `frames_per_root` = 1): the units of a root arrive in rank order = row
+        order, i.e. as the finished frame; nothing else to do.
+      * compact pixel words (`pixel_bytes` = 4, RTX_RENDER_COMPACT): a rank ships 4 instead of S bytes per
+        pixel and the root expands them into records (rtx_expand).  What a root receives from rank r is that
+        rank's rows of its M frames back to back, so frame m is the segment list
+        [(source pixel, destination pixel, pixels) per rank] that `finish` is handed.
 
-    def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2):
-        self.dist, self.rank, self.world = dist, rank, world
-        self.W, self.H, self.S, self.nbuf = width, height, record_size, nbuf
+    Callbacks (device-specific; bench.py supplies the GPU ones, the CPU tests the oracle):
+      render_round(q, b, nframes): queue the rendering of this rank's rows of the round's first `nframes`
+          frames, frame f into `self.unit(b, f)`, ordered before whatever is queued next on the current stream.
+      finish(q, b, work, mine) -> token: `work` is the all-to-all's request, `mine` the list of
+          (m, segments) of the frames rooted here; must arrange for `work` to complete and then expand
+          frame m from `self.recv[b]` into `self.frames[b][m]`; returns an object whose wait() orders the
+          caller after all that (None = nothing to wait for).  Without `finish` the token is `work` itself.
+    Buffers are rings of `nbuf`, so the exchange of a round overlaps the rendering of the next."""
+
+    def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2, frames_per_root=1, pixel_bytes=None,
+                 finish=None):
+        self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.W, self.H, self.S, self.nbuf, self.M = width, height, record_size, nbuf, frames_per_root
+        self.px = record_size if pixel_bytes is None else pixel_bytes
+        self.expanding = self.px != record_size
+        if not self.expanding and frames_per_root != 1:
+            raise ValueError("records land as the finished frame only with one frame per root and round")
+        if self.expanding and finish is None:
+            raise ValueError("compact slabs need a finish callback that expands them")
+        self.finish = finish
         self.bounds = row_bounds(height, world)
         self.row0 = self.bounds[rank]
         self.rows = self.bounds[rank + 1] - self.bounds[rank]
-        self.slab_len = record_size * width * self.rows
-        self.all_slab_len = [slab_bytes(self.bounds, g, width, record_size) for g in range(world)]
-        self.frame_len = record_size * width * height
-        self.send = [torch.zeros(world * self.slab_len, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.unit_len = self.px * width * self.rows
+        self.round_frames = self.M * world
+        self.send = [torch.zeros(self.round_frames * self.unit_len, dtype=torch.uint8, device=device) for _ in range(nbuf)]
         # 20*W*H bytes each: the reference's frame size whatever the mode (PrintMachine.cpp:140)
-        self.frames = [torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
+        self.frames = [[torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(self.M)] for _ in range(nbuf)]
+        self.recv = None
+        if self.expanding:
+            self.recv = [torch.zeros(self.M * self.px * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
         self.nothing = torch.zeros(0, dtype=torch.uint8, device=device)
         self.pending = [None] * nbuf
-        self.where = {}   # frame number -> frame ring index (frames rooted here)
+        self.where = {}   # frame number -> (ring index, m) for frames rooted here
 
     def root_of(self, i):
         return i % self.world
 
-    def slab(self, b, j):
-        return self.send[b][j * self.slab_len:(j + 1) * self.slab_len]
+    def unit(self, b, f):
+        """The send-buffer slot of frame f of a round (this rank's rows of it)."""
+        k = (f % self.world) * self.M + f // self.world
+        return self.send[b][k * self.unit_len:(k + 1) * self.unit_len]
+
+    def frames_for_root(self, j, nframes):
+        """How many of a round's first `nframes` frames are rooted on rank j."""
+        return 0 if nframes <= j else (nframes - j + self.world - 1) // self.world
+
+    def segments(self, m, mine):
+        """Frame m of this root in recv[b] when `mine` frames arrived: (src pixel, dst pixel, pixels) per rank."""
+        segs, src = [], 0
+        for r in range(self.world):
+            rows_r = self.bounds[r + 1] - self.bounds[r]
+            if rows_r:
+                segs.append(((src + m * rows_r) * self.W, self.bounds[r] * self.W, rows_r * self.W))
+            src += mine * rows_r
+        return segs
+
+    def _wait(self, b):
+        if self.pending[b] is not None:   # the exchange (and expansion) that last used ring slot b
+            self.pending[b].wait()
+            self.pending[b] = None
 
     def round(self, q, nframes, render_round):
         b = q % self.nbuf
-        if self.pending[b] is not None:   # the exchange that last read send[b] and wrote frames[b]
-            self.pending[b].wait()
-            self.pending[b] = None
+        self._wait(b)
         render_round(q, b, nframes)
-        ins = [self.slab_len if j < nframes else 0 for j in range(self.world)]
-        if self.rank < nframes:
-            out, outs = self.frames[b][:self.frame_len], self.all_slab_len
-            self.where[q * self.world + self.rank] = b
+        N, M = self.world, self.M
+        ins = [self.frames_for_root(j, nframes) * self.unit_len for j in range(N)]
+        mine = self.frames_for_root(self.rank, nframes)
+        outs = [mine * self.px * self.W * (self.bounds[r + 1] - self.bounds[r]) for r in range(N)]
+        if mine == 0:
+            out = self.nothing
+        elif self.expanding:
+            out = self.recv[b][:sum(outs)]
         else:
-            out, outs = self.nothing, [0] * self.world
-        self.pending[b] = self.dist.all_to_all_single(out, self.send[b][:nframes * self.slab_len], outs, ins, async_op=True)
+            out = self.frames[b][0][:sum(outs)]
+        # units bound for rank j are contiguous and the present ones (m < frames_for_root) come first
+        if nframes == self.round_frames:
+            inp = self.send[b]
+        else:
+            inp = self._present_units(b, nframes)
+        work = self.dist.all_to_all_single(out, inp, outs, ins, async_op=True)
+        for m in range(mine):
+            self.where[q * self.round_frames + m * N + self.rank] = (b, m)
+        if self.finish is not None:
+            self.pending[b] = self.finish(q, b, work, [(m, self.segments(m, mine)) for m in range(mine)] if self.expanding else [])
+        else:
+            self.pending[b] = work
+
+    def _present_units(self, b, nframes):
+        """Partial round: the present units of each destination, packed (all_to_all_single wants one contiguous
+        input).  Only the last round of a run takes this path."""
+        parts = []
+        for j in range(self.world):
+            k = self.frames_for_root(j, nframes)
+            if k:
+                parts.append(self.send[b][j * self.M * self.unit_len:(j * self.M + k) * self.unit_len])
+        if not parts:
+            return self.nothing
+        return self.torch.cat(parts)
 
     def run(self, first_round, count, render_round):
         """`count` frames starting at round `first_round`; returns the next round number."""
         q = first_round
         while count > 0:
-            n = min(self.world, count)
+            n = min(self.round_frames, count)
             self.round(q, n, render_round)
             count -= n
             q += 1
@@ -212,21 +279,20 @@ class RowShardedRounds:
 
     def drain(self):
         for b in range(self.nbuf):
-            if self.pending[b] is not None:
-                self.pending[b].wait()
-                self.pending[b] = None
+            self._wait(b)
 
     def frame(self, i):
         """On the root of frame i: the buffer it was assembled in (valid after drain() and until nbuf more
         rounds have passed)."""
-        return self.frames[self.where[i]]
+        b, m = self.where[i]
+        return self.frames[b][m]
 
 
 def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize):
     """bench.py's timing contract for RowShardedRounds: warm-up, then exactly `steps` frames between
     barrier + synchronize on both sides; returns (MAX over ranks of the elapsed seconds, first timed round)."""
     import time
-    q = pipe.run(0, pipe.world, render_round)   # communicator set-up: one full round, neither timed nor counted
+    q = pipe.run(0, pipe.round_frames, render_round)   # communicator set-up: one full round, neither timed nor counted
     pipe.drain()
     q = pipe.run(q, warmup, render_round)
     pipe.drain()

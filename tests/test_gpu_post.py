@@ -288,3 +288,61 @@ def test_pipelined_update_matches_synchronous_update(R, ctx):
     finally:
         for ptr, _ in bufs:
             ctx.host_free(ptr)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("config", ["C1", "odd"])
+def test_compact_words_expand_to_the_same_records(R, ctx, mode, config):
+    """RTX_RENDER_COMPACT + rtx_expand == the records rtx_render_rows writes == the oracle's, every character mode;
+    the words themselves are checked through the numpy restatement of the 4-byte form (tests/util.py)."""
+    import torch
+    if config == "C1":
+        p, sph, pl = R.config_inputs("C1")
+    else:
+        _, sph, pl = R.config_inputs("C1")
+        p = R.camera_params(333, 77)      # odd width: record rows are not 16-byte multiples (slow store path)
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    S = 20 if mode >= R.RGB_ASCII else 12
+    want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), mode)[:S * W * H]
+    words = torch.full((W * H,), 0x7F7F7F7F, dtype=torch.int32, device="cuda")
+    out = torch.full((S * W * H + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_rows(p, mode, 0, H, d_out=words.data_ptr(), out_row_base=0, flags=R.RENDER_COMPACT)
+    ctx.expand(mode, words.data_ptr(), out.data_ptr(), [(0, 0, W * H)])
+    ctx.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:S * W * H], want), U.first_diff(got[:S * W * H], want, S, W)
+    assert (got[S * W * H:] == 0xEE).all()          # nothing written past the last record
+    w = words.cpu().numpy().view(np.uint32)
+    assert np.array_equal(U.words_to_records(w, S, ord('3') if mode in (0, 2) else ord('4')), want)
+    assert (w.reshape(H, W)[:, W - 1] == 0xFFFFFFFF).all()
+    # several segments, out of order, into a destination that starts mid-buffer: rows swapped pairwise
+    segs = []
+    for r in range(H):
+        segs.append((r * W, (r ^ 1) * W if (r ^ 1) < H else r * W, W))
+    out2 = torch.zeros(S * W * H, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.expand(mode, words.data_ptr(), out2.data_ptr(), segs)
+    ctx.synchronize()
+    got2 = out2.cpu().numpy().reshape(H, W * S)
+    wantr = want.reshape(H, W * S)
+    for r in range(H):
+        rr = (r ^ 1) if (r ^ 1) < H else r
+        assert np.array_equal(got2[rr], wantr[r]), r
+
+
+def test_compact_rejects_what_it_cannot_do(R, ctx):
+    import torch
+    ctx.set_reference_default_scene()
+    p = R.camera_params(64, 16)
+    buf = torch.zeros(20 * 64 * 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with pytest.raises(R.RtxError):
+        ctx.render_rows(p, R.RGB_ASCII, 0, 16, flags=R.RENDER_COMPACT)                       # context's own buffer
+    with pytest.raises(R.RtxError):
+        ctx.render_rows(p, R.SDL, 0, 16, d_out=buf.data_ptr(), flags=R.RENDER_COMPACT)      # SDL writes nothing
+    with pytest.raises(R.RtxError):
+        ctx.expand(R.SDL, buf.data_ptr(), buf.data_ptr(), [(0, 0, 16)])
+    with pytest.raises(R.RtxError):
+        ctx.expand(R.RGB_ASCII, buf.data_ptr() + 2, buf.data_ptr(), [(0, 0, 16)])            # misaligned

@@ -129,7 +129,7 @@ def _frame_params(R, W, H, i):
     return R.camera_params(W, H, pos=(0.05 * i, 0.0, 0.0), rot=(0.0, np.pi + 0.01 * i, 0.0))
 
 
-def _rounds_worker(rank, world, port, steps, warmup, out_path):
+def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path):
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.dirname(here)):
         if p not in sys.path:
@@ -143,29 +143,45 @@ def _rounds_worker(rank, world, port, steps, warmup, out_path):
         W, H = R.CONFIGS["C1"][0], R.CONFIGS["C1"][1]
         mode, S = O.RGB_ASCII, 20
         sc = O.Scene.from_arrays(sph, pl)
-        pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cpu", nbuf=2)
         rendered = []
 
+        def finish(q, b, work, mine):
+            # stands in for "wait on a side stream, then rtx_expand": words -> records, segment by segment
+            work.wait()
+            for m, segs in mine:
+                words = pipe.recv[b].numpy().view(np.uint32)
+                dst = pipe.frames[b][m].numpy()
+                for src_px, dst_px, n in segs:
+                    dst[dst_px * S:(dst_px + n) * S] = U.words_to_records(words[src_px:src_px + n], S, ord("3"))
+            return None
+
+        pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cpu", nbuf=2, frames_per_root=M,
+                                         pixel_bytes=4 if compact else None, finish=finish if compact else None)
+
         def render_round(q, b, nframes):
-            # the oracle stands in for rtx_submit_slabs: this rank's rows of frames q*N .. q*N+nframes-1
-            for j in range(nframes):
-                i = q * world + j
+            # the oracle stands in for rtx_submit_slabs: this rank's rows of the round's first nframes frames
+            for f in range(nframes):
+                i = q * pipe.round_frames + f
                 full = O.render(U.oracle_params(_frame_params(R, W, H, i)), sc, mode, row0=pipe.row0, rows=pipe.rows)
-                pipe.slab(b, j).numpy()[:] = full[pipe.row0 * W * S:(pipe.row0 + pipe.rows) * W * S]
+                slab = full[pipe.row0 * W * S:(pipe.row0 + pipe.rows) * W * S]
+                if compact:
+                    pipe.unit(b, f).numpy().view(np.uint32)[:] = U.records_to_words(slab, W, pipe.rows, S)
+                else:
+                    pipe.unit(b, f).numpy()[:] = slab
                 rendered.append(i)
 
         elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, steps=steps, warmup=warmup, device="cpu",
                                             synchronize=lambda: None)
-        assert elapsed > 0 and len(rendered) == world + warmup + steps
+        assert elapsed > 0 and len(rendered) == pipe.round_frames + warmup + steps
         ok = 1
         # the frames of the last round (still in the ring), wherever they were assembled
-        rounds = -(-steps // world)
+        rounds = -(-steps // pipe.round_frames)
         last_q = q0 + rounds - 1
-        n_last = steps - (rounds - 1) * world
-        for j in range(n_last):
-            i = last_q * world + j
-            assert pipe.root_of(i) == j
-            if j == rank:
+        n_last = steps - (rounds - 1) * pipe.round_frames
+        for f in range(n_last):
+            i = last_q * pipe.round_frames + f
+            assert pipe.root_of(i) == f % world
+            if f % world == rank:
                 want = O.render(U.oracle_params(_frame_params(R, W, H, i)), sc, mode)
                 ok &= int(np.array_equal(pipe.frame(i).numpy(), want))
         t = torch.tensor([ok], dtype=torch.int64)
@@ -176,11 +192,13 @@ def _rounds_worker(rank, world, port, steps, warmup, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,steps,warmup", [(2, 6, 2), (2, 5, 1), (3, 7, 2), (3, 6, 0)])
-def test_bench_round_pipeline_over_gloo(tmp_path, world, steps, warmup):
-    """The loop bench.py runs by default for --gpus N (RowShardedRounds + timed_rounds: one all-to-all per N
-    frames, frame q*N+j assembled on rank j) over gloo with CPU tensors, full and partial last rounds, every
-    frame with its own camera."""
+@pytest.mark.parametrize("world,steps,warmup,M,compact", [
+    (2, 6, 2, 1, False), (2, 5, 1, 1, False), (3, 7, 2, 1, False),
+    (2, 7, 1, 1, True), (2, 9, 3, 2, True), (3, 10, 0, 2, True), (3, 5, 2, 3, True)])
+def test_bench_round_pipeline_over_gloo(tmp_path, world, steps, warmup, M, compact):
+    """The loop bench.py runs by default for --gpus N (RowShardedRounds + timed_rounds: one all-to-all per
+    round of M*N frames, frame m*N+j of a round assembled on rank j) over gloo with CPU tensors: records and
+    compact pixel words (expanded on the root), full and partial last rounds, every frame with its own camera."""
     out = str(tmp_path / "ok.npy")
-    mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, out), nprocs=world, join=True)
+    mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, M, compact, out), nprocs=world, join=True)
     assert int(np.load(out)[0]) == 1

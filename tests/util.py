@@ -94,3 +94,58 @@ def numpy_synth_scene(seed, n_spheres, n_planes, e1, e2):
         [0, -6, 80, 0, 1, 0, 200, 200, 40, e1 * f(60), 30],
     ], dtype=np.float32)
     return sph, planes[:n_planes].copy()
+
+
+# -- compact pixel words (RTX_RENDER_COMPACT, include/rtx.h) in numpy: a checker's restatement of the 4-byte form,
+# derived from the records themselves, so that oracle frames can be turned into words and back.
+_COLOUR_OFFSETS = {20: (7, 11, 15), 12: (7,)}
+
+
+def _digits_to_value(rec, off):
+    d = rec[:, off:off + 3].astype(np.int32)
+    d = np.where(d == 0, 0, d - 48)
+    return (d[:, 0] * 100 + d[:, 1] * 10 + d[:, 2]).astype(np.uint32)
+
+
+def _value_to_digits(v):
+    v = v.astype(np.int32)
+    h, t, u = v // 100, (v // 10) % 10, v % 10
+    out = np.zeros((v.size, 3), dtype=np.uint8)
+    out[:, 0] = np.where(v >= 100, h + 48, 0)   # absent leading digits are NUL, not '0'
+    out[:, 1] = np.where(v >= 10, t + 48, 0)
+    out[:, 2] = u + 48
+    return out
+
+
+def miss_record(S):
+    if S == 20:
+        return np.frombuffer(b"\x1b[48;2;\x00\x000;\x00\x000;\x00\x000m ", dtype=np.uint8)
+    return np.frombuffer(b"\x1b[48;5;\x0016m ", dtype=np.uint8)
+
+
+def records_to_words(buf, W, rows, S):
+    """S-byte records of W*rows pixels -> compact words.  A record equal to the miss record maps to 0 (in the
+    PIXEL modes a black hit is byte-identical to a miss; both expand to the same bytes)."""
+    rec = np.asarray(buf[:W * rows * S]).reshape(W * rows, S)
+    words = np.zeros(W * rows, dtype=np.uint32)
+    for k, off in enumerate(_COLOUR_OFFSETS[S]):
+        words |= _digits_to_value(rec, off) << np.uint32(8 * k)
+    words |= rec[:, S - 1].astype(np.uint32) << np.uint32(24)
+    words[(rec == miss_record(S)).all(axis=1)] = 0
+    words[(rec == 0).all(axis=1)] = 0xFFFFFFFF
+    return words
+
+
+def words_to_records(words, S, hit_kind):
+    """Compact words -> S-byte records; hit_kind = ord('3') for the ASCII modes, ord('4') for the PIXEL ones."""
+    words = np.asarray(words, dtype=np.uint32)
+    n = words.size
+    rec = np.zeros((n, S), dtype=np.uint8)
+    rec[:] = miss_record(S)
+    hit = (words != 0) & (words != 0xFFFFFFFF)
+    rec[hit, 2] = hit_kind
+    for k, off in enumerate(_COLOUR_OFFSETS[S]):
+        rec[hit, off:off + 3] = _value_to_digits((words[hit] >> np.uint32(8 * k)) & np.uint32(255))
+    rec[hit, S - 1] = (words[hit] >> np.uint32(24)).astype(np.uint8)
+    rec[words == 0xFFFFFFFF] = 0
+    return rec.reshape(-1)

@@ -301,22 +301,28 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
 }
 
 // Exact tests of one ray against the candidate list (index is wave-uniform: LDS broadcast reads).
+__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, uint32_t i, Best& best)
+{
+    float s;
+    if (!sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s)) {
+        ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
+        float t;
+        if (sphere_hit(ray, s, sr.w, t)) {
+            const uint32_t ki = s_idx[i];
+            if (t < best.t || (t == best.t && ki < best.k)) {
+                best.t = t;
+                best.k = ki;
+            }
+        }
+    }
+}
+
+// (Requesting the next record one test ahead -- one or two records in flight -- was measured and dropped: 1-2 %
+// slower; with 6 waves per SIMD the LDS latency of the broadcast read is already hidden.)
 __device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best)
 {
     for (uint32_t i = 0; i < total; i++) {
-        const float4 sr = s_rec[i];
-        float s;
-        if (!sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s)) {
-            ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
-            float t;
-            if (sphere_hit(ray, s, sr.w, t)) {
-                const uint32_t ki = s_idx[i];
-                if (t < best.t || (t == best.t && ki < best.k)) {
-                    best.t = t;
-                    best.k = ki;
-                }
-            }
-        }
+        test_candidate(ray, s_rec[i], s_idx, i, best);
     }
 }
 

@@ -34,7 +34,28 @@ template <int KIND> __global__ void k(float* out, float seed)
             asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
         }
         out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
-    } else { // v_pk_mul_f32 / v_pk_add_f32 alternating
+    } else if (KIND == 4) { // v_rcp_f32 (transcendental unit)
+        float x0=a+1,x1=a+2,x2=a+3,x3=a+4,x4=a+5,x5=a+6,x6=a+7,x7=a+8;
+        for (int i = 0; i < ITERS; i++) {
+            x0=__builtin_amdgcn_rcpf(x0); x1=__builtin_amdgcn_rcpf(x1); x2=__builtin_amdgcn_rcpf(x2); x3=__builtin_amdgcn_rcpf(x3);
+            x4=__builtin_amdgcn_rcpf(x4); x5=__builtin_amdgcn_rcpf(x5); x6=__builtin_amdgcn_rcpf(x6); x7=__builtin_amdgcn_rcpf(x7);
+        }
+        out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
+    } else if (KIND == 5) { // v_rsq_f32
+        float x0=a+1,x1=a+2,x2=a+3,x3=a+4,x4=a+5,x5=a+6,x6=a+7,x7=a+8;
+        for (int i = 0; i < ITERS; i++) {
+            x0=__builtin_amdgcn_rsqf(x0); x1=__builtin_amdgcn_rsqf(x1); x2=__builtin_amdgcn_rsqf(x2); x3=__builtin_amdgcn_rsqf(x3);
+            x4=__builtin_amdgcn_rsqf(x4); x5=__builtin_amdgcn_rsqf(x5); x6=__builtin_amdgcn_rsqf(x6); x7=__builtin_amdgcn_rsqf(x7);
+        }
+        out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
+    } else if (KIND == 6) { // one v_rcp_f32 per 7 v_fma_f32: does the transcendental unit overlap the main pipe?
+        float x0=a+1,x1=a+2,x2=a+3,x3=a+4,x4=a+5,x5=a+6,x6=a+7,x7=a+8;
+        for (int i = 0; i < ITERS; i++) {
+            x0=__builtin_amdgcn_rcpf(x0); x1=__builtin_fmaf(x1,b,c); x2=__builtin_fmaf(x2,b,c); x3=__builtin_fmaf(x3,b,c);
+            x4=__builtin_fmaf(x4,b,c); x5=__builtin_fmaf(x5,b,c); x6=__builtin_fmaf(x6,b,c); x7=__builtin_fmaf(x7,b,c);
+        }
+        out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
+    } else if (KIND == 3) { // v_pk_mul_f32 / v_pk_add_f32 alternating
         f2 bb={b,b}, cc={c,c};
         f2 x0={a,a+8},x1={a+1,a+9},x2={a+2,a+10},x3={a+3,a+11},x4={a+4,a+12},x5={a+5,a+13},x6={a+6,a+14},x7={a+7,a+15};
         for (int i = 0; i < ITERS/2; i++) {
@@ -72,5 +93,8 @@ int main()
     run<1>("v_pk_fma_f32", d);
     run<2>("v_mul_f32/v_add_f32", d);
     run<3>("v_pk_mul_f32/v_pk_add_f32", d);
+    run<4>("v_rcp_f32", d);
+    run<5>("v_rsq_f32", d);
+    run<6>("1 v_rcp_f32 : 7 v_fma_f32", d);
     return 0;
 }

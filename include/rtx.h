@@ -95,7 +95,13 @@ enum rtx_render_flags {
      * 0xffffffff = column W-1.  rtx_expand turns the words into the very records rtx_render_rows would have
      * written.  For the row-sharded multi-GPU loop: a rank ships 4 instead of 20 bytes per pixel over xGMI and
      * the GPU that assembles the frame writes the records.  No reference counterpart.  Not with RTX_SDL. */
-    RTX_RENDER_COMPACT = 2
+    RTX_RENDER_COMPACT = 2,
+    /* The output is the 8 floats behind each record instead of the record (32 bytes per pixel, 16-byte aligned
+     * caller's buffer, same row addressing): distance (99999999.f without a hit), shadingValue, normal.xyz,
+     * colour.xyz -- struct RayTraceReturnData (RayTracing.h:17-23) after RayTrace (RayTracing.cu:81-168), i.e.
+     * the values the 1e-5 parity tolerance is stated on.  Normal and colour are defined for pixels with a hit
+     * only; column W-1 is all zero.  For checks, not for the frame loop.  Not with RTX_SDL. */
+    RTX_RENDER_VALUES = 4
 };
 
 /* One run of pixels for rtx_expand: n_pixels words starting at word src_pixel of the compact buffer become

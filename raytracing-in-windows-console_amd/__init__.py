@@ -27,6 +27,7 @@ KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
 OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL = 1, 2, 3, 4
 RENDER_ZERO_TAIL = 1
 RENDER_COMPACT = 2
+RENDER_VALUES = 4
 
 
 class RtxError(RuntimeError):

@@ -253,7 +253,11 @@ __device__ __forceinline__ void record_words(bool visible, const Fields& f, cons
 // is never 0), 0 for a pixel beyond the far plane or without a hit, 0xffffffff for the untraced column W-1.
 constexpr uint32_t kCompactMiss = 0u, kCompactNewline = 0xffffffffu;
 
-template <int MODE>
+// OUT: what a pixel's result is stored as -- a kernel per form, so that the frame loop's kernel carries no
+// trace of the other two.
+enum { kOutRecords = 0, kOutCompact = 1, kOutValues = 2 };
+
+template <int MODE, int OUT>
 __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& cam, const uint32_t* s_digits, const uint8_t* s_ramp, bool in_frame, bool is_newline_col,
                                                  uint32_t row, uint32_t col, float distance, V3 normal, V3 colour, float shadingValue)
 {
@@ -263,11 +267,19 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
         return;
     }
     const bool visible = distance <= cam.far; // RayTracing.cu:207,288,371,508,646
-#ifdef RTX_NO_COMPACT // A/B experiment builds only (make variant)
-    if (false) {
-#else
-    if (a.compact) {
-#endif
+    if (OUT == kOutValues) {
+        // RTX_RENDER_VALUES: the floats behind the record (RayTraceReturnData, RayTracing.h:17-23), for parity checks
+        float4* o = reinterpret_cast<float4*>(a.out) + ((size_t)(row - a.out_row_base) * a.W + col) * 2u;
+        if (is_newline_col) {
+            o[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            o[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            o[0] = make_float4(distance, shadingValue, normal.x, normal.y);
+            o[1] = make_float4(normal.z, colour.x, colour.y, colour.z);
+        }
+        return;
+    }
+    if (OUT == kOutCompact) {
         uint32_t word = kCompactNewline;
         if (!is_newline_col) {
             word = kCompactMiss;
@@ -432,7 +444,7 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
     return it.geom[k];
 }
 
-template <int MODE, bool CULL>
+template <int MODE, bool CULL, int OUT>
 __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
 {
     constexpr int kListCap = CULL ? kListCapCull : kListCapBrute;
@@ -684,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void rtx_trace(const KArgs a)
         }
 
         if (MODE != RTX_K_SDL && !ABL(64u)) {
-            encode_and_store<MODE>(a, cam, s_digits, s_ramp, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
+            encode_and_store<MODE, OUT>(a, cam, s_digits, s_ramp, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
         }
         STAMP(3 + (j < 9u ? j : 9u));
 #ifdef RTX_ABLATE
@@ -933,18 +945,28 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
-#define RTX_LAUNCH(M, C)                                                           \
-    do {                                                                           \
-        hipLaunchKernelGGL((rtx_trace<M, C>), grid, block, 0, stream, *a);         \
-        name = "rtx_trace<" #M "," #C ">";                                         \
+#define RTX_LAUNCH(M, C, O, SUFFIX)                                                  \
+    do {                                                                             \
+        hipLaunchKernelGGL((rtx_trace<M, C, O>), grid, block, 0, stream, *a);        \
+        name = "rtx_trace<" #M "," #C SUFFIX ">";                                    \
     } while (0)
-#define RTX_LAUNCH_MODE(M)        \
-    do {                          \
-        if (cull) {               \
-            RTX_LAUNCH(M, true);  \
-        } else {                  \
-            RTX_LAUNCH(M, false); \
-        }                         \
+#define RTX_LAUNCH_OUT(M, C)                                   \
+    do {                                                       \
+        if (a->compact == 0u) {                                \
+            RTX_LAUNCH(M, C, kOutRecords, "");                 \
+        } else if (a->compact == 1u) {                         \
+            RTX_LAUNCH(M, C, kOutCompact, ",compact");         \
+        } else {                                               \
+            RTX_LAUNCH(M, C, kOutValues, ",values");           \
+        }                                                      \
+    } while (0)
+#define RTX_LAUNCH_MODE(M)            \
+    do {                              \
+        if (cull) {                   \
+            RTX_LAUNCH_OUT(M, true);  \
+        } else {                      \
+            RTX_LAUNCH_OUT(M, false); \
+        }                             \
     } while (0)
     switch (mode) {
     case RTX_K_BIT_ASCII: RTX_LAUNCH_MODE(RTX_K_BIT_ASCII); break;
@@ -952,10 +974,18 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     case RTX_K_RGB_ASCII: RTX_LAUNCH_MODE(RTX_K_RGB_ASCII); break;
     case RTX_K_RGB_PIXEL: RTX_LAUNCH_MODE(RTX_K_RGB_PIXEL); break;
     case RTX_K_RGB_NORMALS: RTX_LAUNCH_MODE(RTX_K_RGB_NORMALS); break;
-    case RTX_K_SDL: RTX_LAUNCH_MODE(RTX_K_SDL); break;
+    case RTX_K_SDL:
+        // RayTrace_SDL stores nothing, whatever the output form
+        if (cull) {
+            RTX_LAUNCH(RTX_K_SDL, true, kOutRecords, "");
+        } else {
+            RTX_LAUNCH(RTX_K_SDL, false, kOutRecords, "");
+        }
+        break;
     default: return nullptr;
     }
 #undef RTX_LAUNCH_MODE
+#undef RTX_LAUNCH_OUT
 #undef RTX_LAUNCH
     *hip_error = (int)hipGetLastError();
     return name;

@@ -412,3 +412,39 @@ def test_odd_frame_sizes_with_culling(R, ctx, res):
         ctx.render_rows(p, R.RGB_ASCII, r0, r1 - r0, d_out=dst.data_ptr(), out_row_base=0)
     ctx.synchronize()
     assert_same(dst.cpu().numpy(), want, O.RGB_ASCII, w, "%dx%d slabs" % (w, h))
+
+
+@pytest.mark.parametrize("config,kernel", [("C1", "auto"), ("C1", "brute"), ("C2", "auto")])
+def test_hit_distances_colours_normals_against_the_oracle(R, ctx, config, kernel):
+    """RTX_RENDER_VALUES: the floats behind the records (distance, shadingValue, normal, colour) next to the
+    oracle's per-pixel values.  north_star's tolerance is 1e-5 (relative) on hit distances and colours; the two
+    sides evaluate the same IEEE operations in the same order, so the stricter check -- bit equality -- holds too."""
+    import torch
+    set_kernel(R, ctx, kernel)
+    p, sph, pl = R.config_inputs(config)
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    rows = H if config == "C1" else 96          # the oracle's per-pixel path is single-threaded
+    row0 = 0 if config == "C1" else 500
+    vals = torch.zeros(W * rows * 8, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_rows(p, R.RGB_ASCII, row0, rows, d_out=vals.data_ptr(), out_row_base=row0, flags=R.RENDER_VALUES)
+    ctx.synchronize()
+    got = vals.cpu().numpy().reshape(rows, W, 8)
+    _, px = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), O.RGB_ASCII, want_pixels=True, row0=row0, rows=rows)
+    px = px[row0:row0 + rows]
+    traced = np.ones((rows, W), dtype=bool)
+    traced[:, -1] = False                      # column W-1 is never traced (RayTracing.cu:187)
+    hit = (px["hit"] != 0) & traced
+    assert hit.sum() > 0.3 * traced.sum()
+    dist_g, dist_o = got[..., 0], px["distance"]
+    # the stated tolerance
+    assert np.all(np.abs(dist_g[hit] - dist_o[hit]) <= TOL_REL * np.abs(dist_o[hit]))
+    assert np.all(np.abs(got[..., 5:8][hit] - px["color"][hit]) <= TOL_REL * 255.0)
+    assert np.all(np.abs(got[..., 2:5][hit] - px["normal"][hit]) <= TOL_REL)
+    # and the stricter one
+    assert np.array_equal(dist_g[traced].view(np.uint32), dist_o[traced].view(np.uint32))     # misses: 99999999.f on both sides
+    assert np.array_equal(got[..., 1][hit].view(np.uint32), px["shading_value"][hit].view(np.uint32))
+    assert np.array_equal(got[..., 2:5][hit].view(np.uint32), px["normal"][hit].view(np.uint32))
+    assert np.array_equal(got[..., 5:8][hit].view(np.uint32), px["color"][hit].view(np.uint32))
+    assert not got[:, -1, :].any()

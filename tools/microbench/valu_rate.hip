@@ -55,6 +55,35 @@ template <int KIND> __global__ void k(float* out, float seed)
             x4=__builtin_fmaf(x4,b,c); x5=__builtin_fmaf(x5,b,c); x6=__builtin_fmaf(x6,b,c); x7=__builtin_fmaf(x7,b,c);
         }
         out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
+    } else if (KIND >= 7 && KIND <= 14) { // one instruction class per kind, 8 independent chains, via inline asm
+        float x0=a+1,x1=a+2,x2=a+3,x3=a+4,x4=a+5,x5=a+6,x6=a+7,x7=a+8;
+#define OP8(TXT) asm volatile(TXT " %0, %0, %8\n\t" TXT " %1, %1, %8\n\t" TXT " %2, %2, %8\n\t" TXT " %3, %3, %8\n\t" \
+                              TXT " %4, %4, %8\n\t" TXT " %5, %5, %8\n\t" TXT " %6, %6, %8\n\t" TXT " %7, %7, %8" \
+                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b))
+        for (int i = 0; i < ITERS; i++) {
+            if (KIND == 7) OP8("v_max_f32");
+            if (KIND == 8) OP8("v_and_b32");
+            if (KIND == 9) OP8("v_add_u32");
+            if (KIND == 10) OP8("v_lshlrev_b32");
+            if (KIND == 11) OP8("v_mul_f32");
+            if (KIND == 12) { // v_cmp_lt_f32 -> vcc, v_cndmask_b32 (2 instructions per chain step)
+                asm volatile("v_cmp_lt_f32 vcc, %0, %8\n\tv_cndmask_b32 %0, %0, %8, vcc\n\tv_cmp_lt_f32 vcc, %1, %8\n\tv_cndmask_b32 %1, %1, %8, vcc\n\t"
+                             "v_cmp_lt_f32 vcc, %2, %8\n\tv_cndmask_b32 %2, %2, %8, vcc\n\tv_cmp_lt_f32 vcc, %3, %8\n\tv_cndmask_b32 %3, %3, %8, vcc"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(b) : "vcc");
+            }
+            if (KIND == 13) { // v_mov_b32 chain (register copies)
+                asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %4\n\t"
+                             "v_mov_b32 %4, %5\n\tv_mov_b32 %5, %6\n\tv_mov_b32 %6, %7\n\tv_mov_b32 %7, %0"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            }
+            if (KIND == 14) { // v_cvt_u32_f32 / v_cvt_f32_u32 alternating
+                asm volatile("v_cvt_u32_f32 %0, %0\n\tv_cvt_f32_u32 %0, %0\n\tv_cvt_u32_f32 %1, %1\n\tv_cvt_f32_u32 %1, %1\n\t"
+                             "v_cvt_u32_f32 %2, %2\n\tv_cvt_f32_u32 %2, %2\n\tv_cvt_u32_f32 %3, %3\n\tv_cvt_f32_u32 %3, %3"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            }
+        }
+#undef OP8
+        out[blockIdx.x*blockDim.x+threadIdx.x]=x0+x1+x2+x3+x4+x5+x6+x7;
     } else if (KIND == 3) { // v_pk_mul_f32 / v_pk_add_f32 alternating
         f2 bb={b,b}, cc={c,c};
         f2 x0={a,a+8},x1={a+1,a+9},x2={a+2,a+10},x3={a+3,a+11},x4={a+4,a+12},x5={a+5,a+13},x6={a+6,a+14},x7={a+7,a+15};
@@ -96,5 +125,13 @@ int main()
     run<4>("v_rcp_f32", d);
     run<5>("v_rsq_f32", d);
     run<6>("1 v_rcp_f32 : 7 v_fma_f32", d);
+    run<11>("v_mul_f32 (asm)", d);
+    run<7>("v_max_f32", d);
+    run<8>("v_and_b32", d);
+    run<9>("v_add_u32", d);
+    run<10>("v_lshlrev_b32", d);
+    run<12>("v_cmp_lt_f32+v_cndmask_b32", d);
+    run<13>("v_mov_b32", d);
+    run<14>("v_cvt_u32_f32/v_cvt_f32_u32", d);
     return 0;
 }

@@ -17,7 +17,15 @@
  * SURVEY.md section 8(c) recorded from the reference's own sources: ten FNV-1a-64 hashes
  * of the full 20*W*H buffer (default scene, five modes, 400x150 and 1920x1080) and
  * the exhaustive 2^24-input hash of ansi256_from_rgb.  tests/test_oracle_pins.py
- * checks all eleven.
+ * checks all eleven.  They cover ray generation, both intersection tests, shading, the
+ * record encoders and the xterm-256 mapper (everything orc_render_rows runs), and
+ * orc_camera_params through the survey's recorded default-camera values.
+ *
+ * PARITY UNPINNED: orc_minimize (RayTracingManager.cu:167-319) and orc_update_objects
+ * (RayTracingManager.cu:10-44, Sphere.cu:15-23).  Neither the reference nor the survey
+ * holds an output of these two for any input, so the restatements are anchored only on
+ * the source text they cite and on what the tests check (tests/test_oracle_minimize.py: a second,
+ * array-level statement of the same rule on real frames, edge cases and newline invariants).
  */
 #ifndef RTX_ORACLE_H
 #define RTX_ORACLE_H

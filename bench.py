@@ -56,8 +56,8 @@ def algorithmic_flops(W, H, ns, npl, hit_frac):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--config", default="C2", help="BASELINE config name (C1..C5); the graded line uses C2")
     ap.add_argument("--mode", default="RGB_ASCII")
     ap.add_argument("--kernel", default="auto", choices=["auto", "brute", "binned"])
@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed, uncounted run-in before the warm-up steps so that the GPU is at its running clocks "
+                         "(N>1: the equivalent number of frames, fixed so that all ranks agree)")
     ap.add_argument("--what", default="trace", choices=["trace", "update", "update-async"],
                     help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
@@ -158,8 +161,25 @@ def main():
                 # one frame per step; rtx_submit_frames queues it on stream i % F (one host call per frame)
                 submit(1, i % F)
 
+        # Clock ramp: an idle MI355X needs some tens of milliseconds of work to reach its running clocks (measured:
+        # 25.3 us per frame when timing starts 5 ms after idle, 20.2 us in steady state).  So the GPU is first kept
+        # busy with the same frames for --prewarm-ms; none of this is timed or counted.
+        n_pre = 0
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+            for _ in range(64):
+                step(n_pre)
+                n_pre += 1
+            if args.what == "update-async":
+                while inflight:
+                    ctx.update_end(inflight.pop(0))
+            ctx.synchronize()
+            torch.cuda.synchronize()
         for i in range(Wm):
             step(i)
+        if args.what == "update-async":
+            while inflight:
+                ctx.update_end(inflight.pop(0))
         ctx.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -237,7 +257,8 @@ def main():
                 if rows:
                     submitters[b](nframes)
 
-            elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize)
+            elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize,
+                                                prewarm=int(args.prewarm_ms * 40))   # ~25 us per frame on one GPU
             n_rounds = -(-K // RF)
             last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
             slab0 = pipe.unit(0, 0)
@@ -252,7 +273,8 @@ def main():
                 # RCCL transfers are ordered after.
                 ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
 
-            elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize)
+            elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize,
+                                            prewarm=int(args.prewarm_ms * 40))
             last_frame = K - 1
             slab0 = pipe.slabs[0] if pipe.slabs is not None else None
             exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
@@ -362,7 +384,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
                                    % (args.config, W, H, ns, npl, args.mode, seed),
-                       "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel,
+                       "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel, "prewarm_ms": args.prewarm_ms,
                        "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs; %s" % (n_gpus, exchange_note)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

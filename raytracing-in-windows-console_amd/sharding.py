@@ -121,13 +121,14 @@ class RowShardedFrames:
         return self.frames[self.where[i]]
 
 
-def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize):
+def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize, prewarm=0):
     """bench.py's timing contract for N > 1: warm-up, then exactly `steps` frames between barrier +
-    synchronize on both sides; returns the MAX over ranks of the elapsed seconds."""
+    synchronize on both sides; returns the MAX over ranks of the elapsed seconds.  `prewarm` more frames run
+    first, neither timed nor counted (clock ramp of an idle GPU; a fixed count so that all ranks agree)."""
     import time
     # communicator set-up (not a timed or counted step): one full rotation of roots, so that every pair of
     # ranks that will exchange slabs has done so once
-    for i in range(pipe.world if pipe.rotate else 1):
+    for i in range((pipe.world if pipe.rotate else 1) + prewarm):
         pipe.step(i, render)
     pipe.drain()
     for i in range(warmup):
@@ -288,11 +289,14 @@ class RowShardedRounds:
         return self.frames[b][m]
 
 
-def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize):
+def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize, prewarm=0):
     """bench.py's timing contract for RowShardedRounds: warm-up, then exactly `steps` frames between
-    barrier + synchronize on both sides; returns (MAX over ranks of the elapsed seconds, first timed round)."""
+    barrier + synchronize on both sides; returns (MAX over ranks of the elapsed seconds, first timed round).
+    `prewarm` more frames run first, neither timed nor counted (clock ramp of an idle GPU; a fixed count so that
+    all ranks agree)."""
     import time
-    q = pipe.run(0, pipe.round_frames, render_round)   # communicator set-up: one full round, neither timed nor counted
+    # communicator set-up: one full round, neither timed nor counted; then the run-in
+    q = pipe.run(0, pipe.round_frames + prewarm, render_round)
     pipe.drain()
     q = pipe.run(q, warmup, render_round)
     pipe.drain()

@@ -100,8 +100,9 @@ def _pipeline_worker(rank, world, port, rotate, out_path):
             calls.append((r0, nrows, base))
 
         steps, warmup = 7, 2
-        elapsed = sharding.timed_frames(dist, torch, pipe, render, steps=steps, warmup=warmup, device="cpu", synchronize=lambda: None)
-        assert elapsed > 0 and len(calls) == steps + warmup + (world if rotate else 1)
+        elapsed = sharding.timed_frames(dist, torch, pipe, render, steps=steps, warmup=warmup, device="cpu", synchronize=lambda: None,
+                                        prewarm=3)
+        assert elapsed > 0 and len(calls) == steps + warmup + (world if rotate else 1) + 3
         want = O.render(op, sc, mode)
         ok = 1
         for i in (steps - 2, steps - 1):  # the last two frames, wherever they were assembled
@@ -171,8 +172,8 @@ def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path):
                 rendered.append(i)
 
         elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, steps=steps, warmup=warmup, device="cpu",
-                                            synchronize=lambda: None)
-        assert elapsed > 0 and len(rendered) == pipe.round_frames + warmup + steps
+                                            synchronize=lambda: None, prewarm=world + 1)
+        assert elapsed > 0 and len(rendered) == pipe.round_frames + (world + 1) + warmup + steps
         ok = 1
         # the frames of the last round (still in the ring), wherever they were assembled
         rounds = -(-steps // pipe.round_frames)

@@ -118,6 +118,9 @@ template <int KIND> void run(const char* name, float* d)
 int main()
 {
     float* d; hipMalloc(&d, 256 * 8 * 256 * sizeof(float));
+    // run-in: an idle MI355X needs tens of milliseconds of work to reach its running clocks
+    for (int r = 0; r < 2000; r++) hipLaunchKernelGGL(k<0>, dim3(256 * 8), dim3(256), 0, 0, d, 1.0f);
+    hipDeviceSynchronize();
     run<0>("v_fma_f32", d);
     run<1>("v_pk_fma_f32", d);
     run<2>("v_mul_f32/v_add_f32", d);

@@ -203,3 +203,40 @@ def test_bench_round_pipeline_over_gloo(tmp_path, world, steps, warmup, M, compa
     out = str(tmp_path / "ok.npy")
     mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, M, compact, out), nprocs=world, join=True)
     assert int(np.load(out)[0]) == 1
+
+
+def test_round_bookkeeping_without_a_process_group():
+    """frames_for_root / unit / segments of RowShardedRounds: pure index arithmetic, checked against a brute-force
+    model for several world sizes, heights and frames per root."""
+    import importlib
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
+    for world, H, M in ((2, 9, 1), (3, 10, 2), (4, 7, 3), (8, 1080, 4), (5, 3, 2)):
+        W, px = 6, 4
+        for rank in range(world):
+            pipe = sharding.RowShardedRounds(None, torch, rank, world, W, H, 20, "cpu", nbuf=1, frames_per_root=M, pixel_bytes=px,
+                                             finish=lambda *a: None)
+            RF = pipe.round_frames
+            assert RF == M * world
+            for nframes in range(0, RF + 1):
+                # frame f of a round is rooted on f % world
+                want = sum(1 for f in range(nframes) if f % world == rank)
+                assert pipe.frames_for_root(rank, nframes) == want
+            # every frame of a round has its own, non-overlapping send slot; slots of one destination are adjacent
+            offs = sorted((pipe.unit(0, f).data_ptr() - pipe.send[0].data_ptr()) for f in range(RF)) if pipe.unit_len else []
+            assert offs == [k * pipe.unit_len for k in range(RF)] or not pipe.unit_len
+            for j in range(world):
+                ks = [((f % world) * M + f // world) for f in range(RF) if f % world == j]
+                assert ks == list(range(j * M, (j + 1) * M))
+            # segments: what arrives from rank r is its rows of the `mine` frames back to back
+            for mine in range(1, M + 1):
+                for m in range(mine):
+                    segs = pipe.segments(m, mine)
+                    covered = 0
+                    for src, dst, n in segs:
+                        r = [g for g in range(world) if pipe.bounds[g] * W == dst and pipe.bounds[g + 1] > pipe.bounds[g]][0]
+                        rows_r = pipe.bounds[r + 1] - pipe.bounds[r]
+                        assert n == rows_r * W
+                        before = sum(mine * (pipe.bounds[g + 1] - pipe.bounds[g]) for g in range(r)) * W
+                        assert src == before + m * rows_r * W
+                        covered += n
+                    assert covered == W * H

@@ -12,6 +12,7 @@ Hashes are standard FNV-1a-64 (offset basis 14695981039346656037) of the full ze
 Usage: python tests/golden/make_golden.py [--big]     (--big adds C3, C4, C5: minutes of CPU)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,6 +37,7 @@ def entry(p, scene, mode, threads):
     rec = buf[:S * W * H].reshape(H, W, S)
     return {
         "frame_fnv1a64": O.fnv1a64(buf),
+        "frame_sha256": hashlib.sha256(buf.tobytes()).hexdigest(),   # for checkers that may not load the oracle (bench.py --verify)
         "minimized_fnv1a64": O.fnv1a64(mini),
         "minimized_bytes": int(mini.size),
         "foreground_pixels": int((rec[:, :W - 1, 2] == ord("3")).sum()) if mode in (O.BIT_ASCII, O.RGB_ASCII) else None,

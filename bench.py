@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--subtiles", type=int, default=0)
     ap.add_argument("--two-level", type=int, default=-1)
+    ap.add_argument("--refine", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="N=1: check the last frame against the golden hash (N>1 does so by default)")
@@ -133,6 +134,7 @@ def main():
     ctx.set_option(R.OPT_TILE_LOG2_W, args.tile)
     ctx.set_option(R.OPT_SUBTILES, args.subtiles)
     ctx.set_option(R.OPT_TWO_LEVEL, args.two_level)
+    ctx.set_option(R.OPT_REFINE, args.refine)
 
     K, Wm = args.steps, args.warmup
     bounds = sharding.row_bounds(H, world)

@@ -44,6 +44,7 @@ struct rtx_ctx {
     int64_t opt_tile_log2w = 0;
     int64_t opt_subtiles = 0;
     int64_t opt_two_level = -1;     // -1 auto, 0 off, 1 on
+    int64_t opt_refine = -1;        // -1 auto, 0 off, 1 on
     // two-level culling scratch, one set per stream that renders (launches on one stream are ordered, so a
     // set is never shared by frames in flight on different streams)
     struct CellScratch {

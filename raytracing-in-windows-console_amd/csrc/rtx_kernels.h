@@ -46,6 +46,7 @@ struct KArgs {
     uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
     uint32_t cells_x;
     uint8_t* out;             // records of row out_row_base start here
+    uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;
                               // 2 = RTX_RENDER_VALUES: out holds 8 floats per pixel (distance, shadingValue, normal, colour)
 #ifdef RTX_ABLATE

@@ -132,10 +132,10 @@ __device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t co
 }
 
 // true when the sphere (hoisted form) provably cannot be hit by any pixel ray of the tile.
-__device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float oy, float oz, float oo, float r)
+__device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float oy, float oz, float oo, float r, float& margin)
 {
     // margin >= R + 3u|otc| + evaluation slack (see kKappa); hardware sqrt is within 1 ulp
-    const float margin = __builtin_amdgcn_sqrtf(r * r * (1.0f + kKappa) + kKappa * oo) + kDelta * __builtin_amdgcn_sqrtf(oo);
+    margin = __builtin_amdgcn_sqrtf(r * r * (1.0f + kKappa) + kKappa * oo) + kDelta * __builtin_amdgcn_sqrtf(oo);
     bool out = false;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
@@ -368,11 +368,12 @@ constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes tak
 template <bool CULL>
 __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
                                                 uint32_t k0, uint32_t k1, float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8],
-                                                uint32_t parity, uint32_t total, bool drop_all)
+                                                uint32_t parity, uint32_t total, bool drop_all, float* s_margin = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep[2];
     float4 rec[2];
+    float mg[2] = {0.0f, 0.0f};
     const float4 g[2] = {g0, g1};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -385,7 +386,11 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         keep[h] = (k < ns) && !drop_all;
         if (CULL) {
             // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
-            keep[h] = keep[h] && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
+            const bool culled = tile_culls(fr, ox, oy, oz, oo, g[h].w, mg[h]);
+            keep[h] = keep[h] && !(cc > 0.0f && culled);
+            if (!(cc > 0.0f)) {
+                mg[h] = __builtin_inff(); // camera inside or on the sphere: never culled, by any pyramid
+            }
         }
     }
     const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
@@ -415,11 +420,13 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         const uint32_t pos = total + before + (uint32_t)__popcll(m0 & below);
         s_rec[pos] = rec[0];
         s_idx[pos] = k0;
+        if (s_margin) s_margin[pos] = mg[0];
     }
     if (keep[1]) {
         const uint32_t pos = total + first_total + before1 + (uint32_t)__popcll(m1 & below);
         s_rec[pos] = rec[1];
         s_idx[pos] = k1;
+        if (s_margin) s_margin[pos] = mg[1];
     }
     return __builtin_amdgcn_readfirstlane(total + sum);
 }
@@ -444,7 +451,13 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
     return it.geom[k];
 }
 
-template <int MODE, bool CULL, int OUT>
+constexpr int kRefineSub = 2;      // REFINE: at most this many sub-tiles (5 + 20 per sub-tile lanes build the pyramids)
+constexpr int kWaveListCap = 192;  // REFINE: candidates a wave keeps for its own 64 pixels; more -> it scans the whole list
+
+// REFINE (dense scenes, long candidate lists): before a wave scans the workgroup's list for its 64 pixels it
+// tests the list, one entry per lane, against the pyramid of just those pixels -- same conservative test and
+// margin as for the macro tile -- and scans the survivors only.
+template <int MODE, bool CULL, int OUT, bool REFINE>
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 7 // 72 VGPRs: 7 workgroups per CU instead of 6 (20.4 -> 19.6 us per frame; 8 needs spills and gains nothing)
 #endif
@@ -460,6 +473,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ uint8_t s_ramp[68];               // the glyph ramp (RayTracing.h:97-115)
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
     __shared__ float s_frustum[16];              // the macro tile's five plane normals
+    __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
+    __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
+    __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
@@ -542,12 +558,25 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     TileFrustum fr;
     if (CULL) {
         if (tid < 64u) {
-            // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along)
-            const V3 n = tile_plane(cam, mcol0, mrow0, mw, mh, tid);
+            // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along) ...
+            uint32_t pc0 = mcol0, pr0 = mrow0, pw = mw, ph = mh, pk = tid;
+            if (REFINE && tid >= 5u) {
+                // ... unless REFINE gives them the pyramids of the 64-pixel pieces: lane 5 + 5*region + k builds
+                // plane k of region = sub-tile * 4 + wave (a wave's pixels: all tw columns, 64/tw rows)
+                const uint32_t q = tid - 5u, region = q / 5u, sub = region >> 2, w = region & 3u;
+                pk = q - region * 5u;
+                pc0 = mcol0 + (sub & (nx - 1u)) * tw;
+                pr0 = mrow0 + (sub >> lnx) * th + w * (64u >> lw);
+                pw = tw;
+                ph = 64u >> lw;
+            }
+            const V3 n = tile_plane(cam, pc0, pr0, pw, ph, pk);
             if (tid < 5u) {
                 s_frustum[3 * tid + 0] = n.x;
                 s_frustum[3 * tid + 1] = n.y;
                 s_frustum[3 * tid + 2] = n.z;
+            } else if (REFINE && tid - 5u < nsub * 20u) {
+                s_wfr[tid - 5u] = make_float4(n.x, n.y, n.z, 0.0f);
             }
         }
         lds_barrier();
@@ -573,7 +602,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             overflow = true; // the list cannot take another step: fall back to one scene walk per sub-tile
             break;
         }
-        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u));
+        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u), REFINE ? s_margin : nullptr);
     }
     if (tid < np_tab) {
         // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
@@ -604,7 +633,48 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         b.t = kNoHit;
         b.k = 0xffffffffu;
         if (!overflow) {
-            if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
+            bool refined = false;
+            if (REFINE && total > 8u) {
+                // this wave's pyramid (uniform reads), then the list, one entry per lane
+                const uint32_t wave = tid >> 6, lane = tid & 63u;
+                V3 wn[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const float4 pn = s_wfr[(j * 4u + wave) * 5u + (uint32_t)k];
+                    wn[k] = v3(pn.x, pn.y, pn.z);
+                }
+                uint32_t cnt = 0;
+                for (uint32_t base = 0; base < total && cnt <= (uint32_t)kWaveListCap; base += 64u) {
+                    const uint32_t i = base + lane;
+                    const uint32_t ii = i < total ? i : total - 1u;
+                    const float4 sr = s_rec[ii];
+                    const float mg = s_margin[ii];
+                    bool out = false;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        out = out || (wn[k].x * sr.x + wn[k].y * sr.y + wn[k].z * sr.z > mg); // as tile_culls
+                    }
+                    const bool keepw = i < total && !out;
+                    const unsigned long long m = __ballot(keepw);
+                    const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (keepw && pos < (uint32_t)kWaveListCap) {
+                        s_wlist[wave][pos] = (uint16_t)i;
+                    }
+                    cnt += (uint32_t)__popcll(m);
+                }
+                cnt = __builtin_amdgcn_readfirstlane(cnt);
+                if (cnt <= (uint32_t)kWaveListCap) {
+                    refined = true;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
+                    for (uint32_t q = 0; q < cnt; q++) {
+                        const uint32_t i = s_wlist[wave][q];
+                        test_candidate(ray, s_rec[i], s_idx, i, b);
+                    }
+                }
+            }
+            if (!refined) {
+                if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
+            }
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
             // the list into the best hit whenever it fills.
@@ -802,7 +872,8 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
             const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
             const float oo = ox * ox + oy * oy + oz * oz;
             const float cc = oo - (g[h].w * g[h].w);
-            keep[h] = (k < hi) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w));
+            float mg_unused;
+            keep[h] = (k < hi) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w, mg_unused));
         }
         const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
         if (lane == 0) {
@@ -948,10 +1019,15 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
-#define RTX_LAUNCH(M, C, O, SUFFIX)                                                  \
-    do {                                                                             \
-        hipLaunchKernelGGL((rtx_trace<M, C, O>), grid, block, 0, stream, *a);        \
-        name = "rtx_trace<" #M "," #C SUFFIX ">";                                    \
+#define RTX_LAUNCH(M, C, O, SUFFIX)                                                          \
+    do {                                                                                     \
+        if (C && a->refine) {                                                                \
+            hipLaunchKernelGGL((rtx_trace<M, C, O, C>), grid, block, 0, stream, *a);         \
+            name = "rtx_trace<" #M "," #C SUFFIX ",refine>";                                 \
+        } else {                                                                             \
+            hipLaunchKernelGGL((rtx_trace<M, C, O, false>), grid, block, 0, stream, *a);     \
+            name = "rtx_trace<" #M "," #C SUFFIX ">";                                        \
+        }                                                                                    \
     } while (0)
 #define RTX_LAUNCH_OUT(M, C)                                   \
     do {                                                       \

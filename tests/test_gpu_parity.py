@@ -39,11 +39,12 @@ def assert_same(got, want, mode, W, what):
 KERNELS = ["brute", "binned"]
 
 
-def set_kernel(R, ctx, kernel, tile=0, subtiles=0, two_level=-1):
+def set_kernel(R, ctx, kernel, tile=0, subtiles=0, two_level=-1, refine=-1):
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, tile)
     ctx.set_option(R.OPT_SUBTILES, subtiles)
     ctx.set_option(R.OPT_TWO_LEVEL, two_level)
+    ctx.set_option(R.OPT_REFINE, refine)
 
 
 # ---------------------------------------------------------------- reference default scene
@@ -310,11 +311,15 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
     want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
     for kernel in KERNELS:
         for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
-            for sub in ((0,) if kernel == "brute" else (1, 4, 8)):
+            for sub in ((0,) if kernel == "brute" else (1, 2, 4, 8)):
                 for two in ((0,) if kernel == "brute" else (0, 1)):
-                    set_kernel(R, ctx, kernel, tile, sub, two)
-                    got = ctx.render_to_host(p, R.RGB_ASCII)
-                    assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d two-level %d" % (seed, kernel, tile, sub, two))
+                    for refine in ((0, 1) if kernel == "binned" and sub <= 2 else (0,)):
+                        set_kernel(R, ctx, kernel, tile, sub, two, refine)
+                        got = ctx.render_to_host(p, R.RGB_ASCII)
+                        assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d two-level %d refine %d"
+                                    % (seed, kernel, tile, sub, two, refine))
+                        if refine:
+                            assert ctx.last_kernel.endswith(",refine>")
 
 
 def test_per_pixel_values_within_tolerance(R, ctx):
@@ -448,3 +453,43 @@ def test_hit_distances_colours_normals_against_the_oracle(R, ctx, config, kernel
     assert np.array_equal(got[..., 2:5][hit].view(np.uint32), px["normal"][hit].view(np.uint32))
     assert np.array_equal(got[..., 5:8][hit].view(np.uint32), px["color"][hit].view(np.uint32))
     assert not got[:, -1, :].any()
+
+
+@pytest.mark.parametrize("mode", [O.BIT_ASCII, O.RGB_ASCII, O.RGB_NORMALS])
+@pytest.mark.parametrize("sub,tile", [(1, 4), (2, 4), (2, 3), (2, 6), (1, 2)])
+def test_per_wave_refinement_gives_the_same_frame(R, ctx, mode, sub, tile):
+    """RTX_OPT_REFINE: each wave narrows the workgroup's candidate list to its own 64 pixels before scanning it.
+    C2 (long lists when forced to few, large tiles) with and without it, against the golden hash / the oracle."""
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    frames = []
+    for refine in (0, 1):
+        set_kernel(R, ctx, "binned", tile, sub, 0, refine)
+        frames.append(ctx.render_to_host(p, mode))
+        assert ctx.last_kernel.endswith(",refine>") == bool(refine)
+    set_kernel(R, ctx, "auto")
+    assert np.array_equal(frames[0], frames[1])
+    g = U.load_golden().get("C2_%s" % O.MODE_NAMES[mode])
+    if g:
+        assert O.fnv1a64(frames[1]) == g["frame_fnv1a64"]
+
+
+def test_refinement_with_more_survivors_than_a_wave_keeps(R, ctx):
+    """Hundreds of spheres stacked on the same pixels: a wave's refined list overflows its 192 slots and the
+    wave must fall back to the whole list."""
+    rng = np.random.default_rng(11)
+    n = 600
+    z = np.sort(rng.uniform(20, 200, n))[::-1]
+    centres = np.stack([rng.normal(0, 0.5, n), rng.normal(0, 0.2, n), z], axis=1)
+    radii = rng.uniform(2.0, 5.0, n)
+    cols = np.floor(rng.uniform(1, 256, (n, 3)))
+    sph = np.concatenate([centres, radii[:, None], cols], axis=1).astype(np.float32)
+    pl = np.zeros((0, 11), dtype=np.float32)
+    ctx.set_scene(sph, pl)
+    p = R.camera_params(192, 64)
+    want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), O.RGB_ASCII, threads=8)
+    for sub in (1, 2):
+        set_kernel(R, ctx, "binned", 4, sub, 0, 1)
+        got = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(got, want, O.RGB_ASCII, 192, "refine overflow sub %d" % sub)
+    set_kernel(R, ctx, "auto")

@@ -74,7 +74,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "brute", "binned"])
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--subtiles", type=int, default=0)
-    ap.add_argument("--two-level", type=int, default=-1)
+    ap.add_argument("--two-level", type=int, default=-1, help="-1 auto, 0 off, 1 on, 2 on with block binning")
     ap.add_argument("--refine", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -79,7 +79,8 @@ enum rtx_option {
     RTX_OPT_KERNEL = 1,       /* enum rtx_kernel */
     RTX_OPT_TILE_LOG2_W = 2,  /* log2 of the sub-tile width in pixels (2..6; a sub-tile is 256 pixels); 0 = choose from the camera */
     RTX_OPT_SUBTILES = 3,     /* sub-tiles per workgroup in the binned kernel (1, 2, 4, 8, 16); 0 = default */
-    RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel: -1 auto (large scenes), 0 off, 1 on */
+    RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel: -1 auto (large scenes), 0 off, 1 on,
+                               * 1 on (single pass), 2 on with the cells binned through blocks of 4x4 cells (auto does so from 16384 spheres) */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 2 sub-tiles per workgroup; otherwise it stays off) */
 };

@@ -51,7 +51,9 @@ struct rtx_ctx {
         hipStream_t stream = nullptr;
         uint32_t* list = nullptr;
         uint32_t* count = nullptr;
-        size_t list_words = 0, count_words = 0;
+        size_t list_words = 0, count_words = 0;   // count holds the cells' counters, then the parent cells' (one memset)
+        uint32_t* parent_list = nullptr;          // hierarchical binning (very large scenes): lists of the 4x4-cell blocks
+        size_t parent_words = 0;
     };
     std::vector<CellScratch> cell_scratch;
 

@@ -45,6 +45,11 @@ struct KArgs {
     uint32_t* cell_count_out;
     uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
     uint32_t cells_x;
+    // rtx_bin_cells input: every sphere (bin_in_list == nullptr), or the list of the parent cell -- a block of
+    // 2^bin_in_shift x 2^bin_in_shift cells binned by a previous, coarser rtx_bin_cells launch (stride ns, like cell_list)
+    const uint32_t* bin_in_list;
+    const uint32_t* bin_in_count;
+    uint32_t bin_in_shift, bin_in_px;  // bin_in_px: parent cells per row
     uint8_t* out;             // records of row out_row_base start here
     uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;

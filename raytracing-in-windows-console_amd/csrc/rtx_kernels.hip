@@ -847,20 +847,31 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
 
     uint32_t* out = a.cell_list_out + (size_t)cell * a.ns;
     uint32_t* count = a.cell_count_out + cell;
-    // this workgroup's share of the spheres: [lo, hi), a multiple of the step size except at the end
-    const uint32_t ns = a.ns, splits = gridDim.z;
+    // what this cell is binned from: the whole scene, or the list of its parent cell (a coarser launch's output)
+    Items items;
+    items.geom = a.sph_geom;
+    items.list = nullptr;
+    items.count = a.ns;
+    if (a.bin_in_list != nullptr) {
+        const uint32_t parent = (blockIdx.y >> a.bin_in_shift) * a.bin_in_px + (blockIdx.x >> a.bin_in_shift);
+        items.list = a.bin_in_list + (size_t)parent * a.ns;
+        items.count = a.bin_in_count[parent];
+    }
+    // this workgroup's share of the items: [lo, hi), a multiple of the step size except at the end
+    const uint32_t ns = items.count, splits = gridDim.z;
     const uint32_t steps = (ns + kChunk - 1) / kChunk;
     const uint32_t lo = (uint32_t)(((uint64_t)steps * blockIdx.z) / splits) * kChunk;
     const uint32_t hi_raw = (uint32_t)(((uint64_t)steps * (blockIdx.z + 1)) / splits) * kChunk;
     const uint32_t hi = hi_raw < ns ? hi_raw : ns;
 
     uint32_t total = 0, parity = 0;
-    float4 g0 = a.sph_geom[lo + tid < ns ? lo + tid : ns - 1u], g1 = a.sph_geom[lo + kThreads + tid < ns ? lo + kThreads + tid : ns - 1u];
+    uint32_t k0, k1;
+    float4 g0 = load_item(items, lo + tid, k0), g1 = load_item(items, lo + kThreads + tid, k1);
     for (uint32_t base = lo; base < hi; base += kChunk, parity ^= 1u) {
         const float4 g[2] = {g0, g1};
-        const uint32_t n0 = base + kChunk + tid, n1 = n0 + kThreads;
-        g0 = a.sph_geom[n0 < ns ? n0 : ns - 1u];
-        g1 = a.sph_geom[n1 < ns ? n1 : ns - 1u];
+        const uint32_t kk[2] = {k0, k1};
+        g0 = load_item(items, base + kChunk + tid, k0);
+        g1 = load_item(items, base + kChunk + kThreads + tid, k1);
         if (total > (uint32_t)(kBinCap - kChunk)) {
             bin_flush(s_out, total, out, count, &s_base);
             total = 0;
@@ -894,10 +905,10 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         if (keep[0]) {
-            s_out[total + before + (uint32_t)__popcll(m0 & below)] = base + tid;
+            s_out[total + before + (uint32_t)__popcll(m0 & below)] = kk[0];
         }
         if (keep[1]) {
-            s_out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = base + kThreads + tid;
+            s_out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = kk[1];
         }
         total = __builtin_amdgcn_readfirstlane(total + sum);
     }

@@ -134,7 +134,7 @@ def test_c3_brute_equals_binned(R, ctx):
         assert_same(b, a, R.RGB_ASCII, int(p.x), "C3 binned (two-level %d) vs brute" % two)
 
 
-@pytest.mark.parametrize("two", [0, 1])
+@pytest.mark.parametrize("two", [0, 1, 2])
 @pytest.mark.parametrize("mode", [O.BIT_ASCII, O.RGB_ASCII, O.RGB_NORMALS])
 def test_two_level_culling_on_c2(R, ctx, mode, two):
     p, sph, pl = R.config_inputs("C2")
@@ -312,7 +312,7 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
     for kernel in KERNELS:
         for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
             for sub in ((0,) if kernel == "brute" else (1, 2, 4, 8)):
-                for two in ((0,) if kernel == "brute" else (0, 1)):
+                for two in ((0,) if kernel == "brute" else (0, 1, 2)):
                     for refine in ((0, 1) if kernel == "binned" and sub <= 2 else (0,)):
                         set_kernel(R, ctx, kernel, tile, sub, two, refine)
                         got = ctx.render_to_host(p, R.RGB_ASCII)

@@ -82,7 +82,7 @@ enum rtx_option {
     RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel: -1 auto (large scenes), 0 off, 1 on,
                                * 1 on (single pass), 2 on with the cells binned through blocks of 4x4 cells (auto does so from 16384 spheres) */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
-                               * (needs at most 2 sub-tiles per workgroup; otherwise it stays off) */
+                               * (needs at most 4 sub-tiles per workgroup; otherwise it stays off) */
 };
 
 /* Flags of rtx_render_rows. */

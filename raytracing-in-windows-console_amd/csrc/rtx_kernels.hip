@@ -451,7 +451,7 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
     return it.geom[k];
 }
 
-constexpr int kRefineSub = 2;      // REFINE: at most this many sub-tiles (5 + 20 per sub-tile lanes build the pyramids)
+constexpr int kRefineSub = 4;      // REFINE: at most this many sub-tiles (lanes 5 .. 5 + 20 per sub-tile build the pyramids)
 constexpr int kWaveListCap = 192;  // REFINE: candidates a wave keeps for its own 64 pixels; more -> it scans the whole list
 
 // REFINE (dense scenes, long candidate lists): before a wave scans the workgroup's list for its 64 pixels it
@@ -557,7 +557,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // up from LDS into scalar registers.
     TileFrustum fr;
     if (CULL) {
-        if (tid < 64u) {
+        const uint32_t plane_lanes = REFINE ? 5u + nsub * 20u : 5u;
+        if (tid < ((plane_lanes + 63u) & ~63u)) { // wave 0, and wave 1 as well when REFINE needs more than 64 lanes
             // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along) ...
             uint32_t pc0 = mcol0, pr0 = mrow0, pw = mw, ph = mh, pk = tid;
             if (REFINE && tid >= 5u) {

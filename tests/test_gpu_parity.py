@@ -313,7 +313,7 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
         for tile in ((0, 6) if kernel == "brute" else (0, 2, 4, 6)):
             for sub in ((0,) if kernel == "brute" else (1, 2, 4, 8)):
                 for two in ((0,) if kernel == "brute" else (0, 1, 2)):
-                    for refine in ((0, 1) if kernel == "binned" and sub <= 2 else (0,)):
+                    for refine in ((0, 1) if kernel == "binned" and sub <= 4 else (0,)):
                         set_kernel(R, ctx, kernel, tile, sub, two, refine)
                         got = ctx.render_to_host(p, R.RGB_ASCII)
                         assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d two-level %d refine %d"
@@ -456,7 +456,7 @@ def test_hit_distances_colours_normals_against_the_oracle(R, ctx, config, kernel
 
 
 @pytest.mark.parametrize("mode", [O.BIT_ASCII, O.RGB_ASCII, O.RGB_NORMALS])
-@pytest.mark.parametrize("sub,tile", [(1, 4), (2, 4), (2, 3), (2, 6), (1, 2)])
+@pytest.mark.parametrize("sub,tile", [(1, 4), (2, 4), (2, 3), (2, 6), (1, 2), (4, 4), (4, 3), (3, 4)])
 def test_per_wave_refinement_gives_the_same_frame(R, ctx, mode, sub, tile):
     """RTX_OPT_REFINE: each wave narrows the workgroup's candidate list to its own 64 pixels before scanning it.
     C2 (long lists when forced to few, large tiles) with and without it, against the golden hash / the oracle."""
@@ -488,7 +488,7 @@ def test_refinement_with_more_survivors_than_a_wave_keeps(R, ctx):
     ctx.set_scene(sph, pl)
     p = R.camera_params(192, 64)
     want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), O.RGB_ASCII, threads=8)
-    for sub in (1, 2):
+    for sub in (1, 2, 4):
         set_kernel(R, ctx, "binned", 4, sub, 0, 1)
         got = ctx.render_to_host(p, R.RGB_ASCII)
         assert_same(got, want, O.RGB_ASCII, 192, "refine overflow sub %d" % sub)

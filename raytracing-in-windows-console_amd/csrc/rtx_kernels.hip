@@ -791,11 +791,13 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
 // does not matter: the closest hit is the minimum of (t, creation index).
 constexpr int kBinCap = 2048; // indices gathered in LDS between flushes
 
-__device__ __forceinline__ void bin_flush(uint32_t* s_out, uint32_t n, uint32_t* out, uint32_t* count, uint32_t* s_base)
+// `owned`: this workgroup is the only one that writes the cell's list (one split), `written` entries so far: no
+// atomic and no zeroed counter needed; the caller stores the final count.
+__device__ __forceinline__ void bin_flush(uint32_t* s_out, uint32_t n, uint32_t* out, uint32_t* count, uint32_t* s_base, bool owned, uint32_t written)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        *s_base = atomicAdd(count, n);
+        *s_base = owned ? written : atomicAdd(count, n);
     }
     __syncthreads();
     const uint32_t base = *s_base;
@@ -865,6 +867,8 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
     const uint32_t hi_raw = (uint32_t)(((uint64_t)steps * (blockIdx.z + 1)) / splits) * kChunk;
     const uint32_t hi = hi_raw < ns ? hi_raw : ns;
 
+    const bool owned = gridDim.z == 1u;
+    uint32_t written = 0;
     uint32_t total = 0, parity = 0;
     uint32_t k0, k1;
     float4 g0 = load_item(items, lo + tid, k0), g1 = load_item(items, lo + kThreads + tid, k1);
@@ -874,7 +878,8 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         g0 = load_item(items, base + kChunk + tid, k0);
         g1 = load_item(items, base + kChunk + kThreads + tid, k1);
         if (total > (uint32_t)(kBinCap - kChunk)) {
-            bin_flush(s_out, total, out, count, &s_base);
+            bin_flush(s_out, total, out, count, &s_base, owned, written);
+            written += total;
             total = 0;
         }
         bool keep[2];
@@ -914,7 +919,11 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         total = __builtin_amdgcn_readfirstlane(total + sum);
     }
     if (total) {
-        bin_flush(s_out, total, out, count, &s_base);
+        bin_flush(s_out, total, out, count, &s_base, owned, written);
+        written += total;
+    }
+    if (owned && tid == 0u) {
+        *count = written;
     }
 }
 

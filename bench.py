@@ -38,6 +38,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+BASELINE_METRIC = "Mrays/s (primary rays) at 1920\u00d71080, 1024 spheres; 1/2/4/8 GPU"   # BASELINE.json "metric", verbatim
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak counts FMA as 2; this path may not contract, so 78.65 Tops/s
 
@@ -391,7 +392,7 @@ def main():
                                         "sample": "rows %d..%d of the same frame; %.2f s wall" % ((H - rows1) // 2, (H - rows1) // 2 + rows1, dt1)}
 
         out = {
-            "metric": "Mrays/s (primary rays) at 1920x1080, 1024 spheres; 1/2/4/8 GPU",
+            "metric": BASELINE_METRIC,
             "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
             "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -375,8 +375,16 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
     float4 rec[2];
     float mg[2] = {0.0f, 0.0f};
     const float4 g[2] = {g0, g1};
+    // the second half of the step is empty when at most 256 items are left (short cell lists, the tail of a scene):
+    // skip its arithmetic (uniform branch)
+    const bool second_half_empty = base + (uint32_t)kThreads >= ns;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
+        if (h == 1 && second_half_empty) {
+            keep[1] = false;
+            rec[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            break;
+        }
         const uint32_t k = base + (uint32_t)h * kThreads + tid; // item number; valid while below ns (the item count)
         // objectToCam = origin - spherePos; c = Dot(otc,otc) - r*r   (Sphere.cu:34-37)
         const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;

@@ -201,6 +201,8 @@ class RowShardedRounds:
         self.nothing = torch.zeros(0, dtype=torch.uint8, device=device)
         self.pending = [None] * nbuf
         self.where = {}   # frame number -> (ring index, m) for frames rooted here
+        self._mine_cache = {}
+        self._full_splits = None
 
     def root_of(self, i):
         return i % self.world
@@ -234,9 +236,14 @@ class RowShardedRounds:
         self._wait(b)
         render_round(q, b, nframes)
         N, M = self.world, self.M
-        ins = [self.frames_for_root(j, nframes) * self.unit_len for j in range(N)]
-        mine = self.frames_for_root(self.rank, nframes)
-        outs = [mine * self.px * self.W * (self.bounds[r + 1] - self.bounds[r]) for r in range(N)]
+        if nframes == self.round_frames and self._full_splits is not None:
+            ins, mine, outs = self._full_splits
+        else:
+            ins = [self.frames_for_root(j, nframes) * self.unit_len for j in range(N)]
+            mine = self.frames_for_root(self.rank, nframes)
+            outs = [mine * self.px * self.W * (self.bounds[r + 1] - self.bounds[r]) for r in range(N)]
+            if nframes == self.round_frames:
+                self._full_splits = (ins, mine, outs)
         if mine == 0:
             out = self.nothing
         elif self.expanding:
@@ -251,8 +258,11 @@ class RowShardedRounds:
         work = self.dist.all_to_all_single(out, inp, outs, ins, async_op=True)
         for m in range(mine):
             self.where[q * self.round_frames + m * N + self.rank] = (b, m)
+            self.where.pop((q - self.nbuf) * self.round_frames + m * N + self.rank, None)   # overwritten by now
         if self.finish is not None:
-            self.pending[b] = self.finish(q, b, work, [(m, self.segments(m, mine)) for m in range(mine)] if self.expanding else [])
+            if mine not in self._mine_cache:   # the segment lists depend on `mine` only: built once
+                self._mine_cache[mine] = [(m, self.segments(m, mine)) for m in range(mine)] if self.expanding else []
+            self.pending[b] = self.finish(q, b, work, self._mine_cache[mine])
         else:
             self.pending[b] = work
 

@@ -218,6 +218,13 @@ int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int 
 int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics, void* host_out, int* ticket);
 int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes);
 
+/* ---- ansi256_from_rgb (ANSIRGB.h:141-189) on its own: the xterm-256 index (16..255) of each packed 0xRRGGBB
+ * value first_rgb, first_rgb+1, ..., first_rgb+count-1 (first_rgb + count <= 2^24), one byte per value into
+ * d_out (device memory of the caller), computed by the very device function and grey lookup the two 8-bit trace
+ * kernels use (RayTracing.cu:210,291).  Lets a checker cover all 2^24 inputs, which no frame does.  Asynchronous
+ * on `stream` (NULL = the context's). */
+int rtx_ansi256_map(rtx_ctx* ctx, uint32_t first_rgb, size_t count, void* d_out, void* stream);
+
 /* ---- pinned host memory for the buffers Update copies into (m_minimizedResultArray / m_hostResultArray,
  * RayTracingManager.cu:62-66, which the reference allocates pageable): device-to-host copies into it run at
  * PCIe rate instead of through a staging bounce.  Optional: any host pointer is accepted by rtx_update. */

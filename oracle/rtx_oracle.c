@@ -658,6 +658,14 @@ uint64_t orc_ansi256_exhaustive_hash(uint64_t h)
     return h;
 }
 
+/* out[i] = orc_ansi256_from_rgb(first + i), i < count: the byte sequence the device mapper is compared with */
+void orc_ansi256_fill(uint32_t first, size_t count, uint8_t* out)
+{
+    for (size_t i = 0; i < count; i++) {
+        out[i] = orc_ansi256_from_rgb(first + (uint32_t)i);
+    }
+}
+
 /* ---------------------------------------------------------------- Camera3D --------- */
 
 /* Camera3D.cpp:8-48 (projection scalars), :51-98 (basis + "view" matrix), :207-376 (cofactor

@@ -130,6 +130,8 @@ uint64_t orc_fnv1a64(const void* data, size_t n);
 
 /* FNV-1a-64 (from `offset_basis`) over orc_ansi256_from_rgb(0 .. 2^24-1), one output byte per input. */
 uint64_t orc_ansi256_exhaustive_hash(uint64_t offset_basis);
+/* out[i] = orc_ansi256_from_rgb(first + i) for i < count. */
+void orc_ansi256_fill(uint32_t first, size_t count, uint8_t* out);
 
 #ifdef __cplusplus
 }

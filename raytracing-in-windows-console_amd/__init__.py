@@ -80,6 +80,7 @@ _SIGNATURES = [
     ("rtx_update", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_size_t)]),
     ("rtx_update_begin", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_int)]),
     ("rtx_update_end", C.c_int, [_P, C.c_int, C.POINTER(C.c_size_t)]),
+    ("rtx_ansi256_map", C.c_int, [_P, C.c_uint32, C.c_size_t, _P, _P]),
     ("rtx_host_alloc", _P, [_P, C.c_size_t]),
     ("rtx_host_free", None, [_P, _P]),
     ("rtx_timer_start", C.c_int, [_P]),
@@ -383,6 +384,10 @@ class Context:
         n = C.c_size_t()
         self._check(lib().rtx_update(self._h, C.byref(params), mode, dt, 1 if run_physics else 0, ptr, C.byref(n)))
         return arr[:n.value]  # a view of the pinned buffer: valid until the next update()
+
+    def ansi256_map(self, first_rgb, count, d_out, stream=None):
+        """rtx_ansi256_map: xterm-256 indices of packed 0xRRGGBB values first_rgb .. first_rgb+count-1 into d_out."""
+        self._check(lib().rtx_ansi256_map(self._h, first_rgb, count, d_out, stream))
 
     def host_alloc(self, nbytes):
         """Pinned host buffer as (pointer, uint8 numpy view); freed with host_free or at close()."""

@@ -2,6 +2,7 @@
 // UpdateObjects (RayTracingManager.cu:10-44, 89-107) and Minimize (RayTracingManager.cu:167-319),
 // plus rtx_update, the whole of Update in one call.
 #include "rtx_ctx.h"
+#include "rtx_device.hpp"
 
 #include <cstring>
 
@@ -35,6 +36,30 @@ __global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, flo
     mv.x = __uint_as_float((uint32_t)mover);
     geom[i] = g;
     motion[i] = mv;
+}
+
+// ---------------------------------------------------------------- ansi256_from_rgb over a range of inputs
+// The mapper of the 8-bit trace kernels (rtx_device.hpp, ANSIRGB.h:141-189) applied to packed 0xRRGGBB values
+// first .. first+count-1, four per thread, one dword store each.
+__global__ __launch_bounds__(kThreads) void rtx_ansi_map(uint32_t first, uint64_t count, const uint8_t* grey, uint8_t* out)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4u;
+    if (i0 >= count) {
+        return;
+    }
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t rgb = first + (uint32_t)i0 + k;
+        v[k] = ansi256_from_rgb((rgb >> 16) & 255u, (rgb >> 8) & 255u, rgb & 255u, grey);
+    }
+    if (i0 + 4u <= count && (((uintptr_t)(out + i0)) & 3u) == 0u) {
+        *reinterpret_cast<uint32_t*>(out + i0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    } else {
+        for (uint32_t k = 0; k < 4u && i0 + k < count; k++) {
+            out[i0 + k] = (uint8_t)v[k];
+        }
+    }
 }
 
 // ---------------------------------------------------------------- Minimize
@@ -401,6 +426,20 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
 
 void* rtx_minimized_device_ptr(rtx_ctx* ctx) { return ctx ? ctx->d_min : nullptr; }
 
+int rtx_ansi256_map(rtx_ctx* ctx, uint32_t first_rgb, size_t count, void* d_out, void* stream_v)
+{
+    if (!ctx || (count && !d_out)) return RTX_ERR_INVALID_ARGUMENT;
+    if ((uint64_t)first_rgb + (uint64_t)count > (1ull << 24)) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_ansi256_map: range exceeds 2^24 colours");
+    if (count == 0) return RTX_OK;
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : ctx->stream;
+    const uint64_t threads = ((uint64_t)count + 3u) / 4u;
+    const unsigned blocks = (unsigned)((threads + rtx::kThreads - 1) / rtx::kThreads);
+    hipLaunchKernelGGL(rtx::rtx_ansi_map, dim3(blocks), dim3(rtx::kThreads), 0, st, first_rgb, (uint64_t)count, ctx->d_grey, (uint8_t*)d_out);
+    RTX_HIP(ctx, hipGetLastError());
+    return RTX_OK;
+}
+
 int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, void* d_out, size_t* out_bytes)
 {
     if (!ctx || !out_bytes) return RTX_ERR_INVALID_ARGUMENT;
@@ -462,14 +501,28 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     rtx_ctx::UpdateSlot& sl = ctx->upd[si];
     if (sl.busy) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_update_begin: both slots are in flight; call rtx_update_end first");
     if (!ctx->copy_stream) RTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // every member under its own null check: a call that fails half-way (out of memory) leaves a slot the next
+    // call completes, instead of one that looks initialised with null buffers behind it
     if (!sl.d_frame) {
-        RTX_HIP(ctx, hipMalloc((void**)&sl.d_frame, ctx->capacity));
-        RTX_HIP(ctx, hipMemsetAsync(sl.d_frame, 0, ctx->capacity, ctx->stream));
-        RTX_HIP(ctx, hipMalloc((void**)&sl.d_min, ctx->capacity));
-        RTX_HIP(ctx, hipHostMalloc((void**)&sl.h_total, sizeof(uint64_t), hipHostMallocDefault));
-        RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming));
-        RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
+        uint8_t* f = nullptr;
+        if (hipMalloc((void**)&f, ctx->capacity) != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for an update slot's frame");
+        const hipError_t me = hipMemsetAsync(f, 0, ctx->capacity, ctx->stream);
+        if (me != hipSuccess) {
+            hipFree(f);
+            return rtx_hip_fail(ctx, me, "hipMemsetAsync(update slot frame)");
+        }
+        sl.d_frame = f;
     }
+    if (!sl.d_min && hipMalloc((void**)&sl.d_min, ctx->capacity) != hipSuccess) {
+        sl.d_min = nullptr;
+        return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for an update slot's minimise buffer");
+    }
+    if (!sl.h_total && hipHostMalloc((void**)&sl.h_total, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+        sl.h_total = nullptr;
+        return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipHostMalloc failed for an update slot");
+    }
+    if (!sl.ev_ready) RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_ready, hipEventDisableTiming));
+    if (!sl.ev_copied) RTX_HIP(ctx, hipEventCreateWithFlags(&sl.ev_copied, hipEventDisableTiming));
     const uint64_t n_slots = (uint64_t)w * h;
     const size_t n_blocks = (size_t)((n_slots + rtx::kSlotsPerBlock - 1) / rtx::kSlotsPerBlock);
     const size_t need = n_blocks * (sizeof(uint32_t) + sizeof(uint64_t)) + 64;

@@ -83,6 +83,8 @@ def lib():
         L.orc_fnv1a64_from.restype = C.c_uint64
         L.orc_ansi256_exhaustive_hash.argtypes = [C.c_uint64]
         L.orc_ansi256_exhaustive_hash.restype = C.c_uint64
+        L.orc_ansi256_fill.argtypes = [C.c_uint32, C.c_size_t, C.c_void_p]
+        L.orc_ansi256_fill.restype = None
         _lib = L
     return _lib
 
@@ -197,6 +199,13 @@ def minimize(mode, buf, w, h):
     out = np.zeros(buf.size + 1, dtype=np.uint8)
     n = lib().orc_minimize(mode, buf.ctypes.data, buf.size, w, h, out.ctypes.data)
     return out[:n].copy()
+
+
+def ansi256_table(first=0, count=1 << 24):
+    """orc_ansi256_from_rgb over packed 0xRRGGBB values first .. first+count-1, one byte each."""
+    out = np.zeros(count, dtype=np.uint8)
+    lib().orc_ansi256_fill(first, count, out.ctypes.data)
+    return out
 
 
 FNV_OFFSET_STANDARD = 14695981039346656037

@@ -94,6 +94,57 @@ def test_camera_inverse_is_an_inverse():
     assert np.allclose(inv @ m, np.eye(4), atol=1e-5)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_camera_params_against_an_independent_numpy_inverse(seed):
+    """rtx_camera_params and orc_camera_params carry the same sixteen cofactor lines (the reference's own term
+    order, Camera3D.cpp:207-376), so comparing them is twin against twin.  Here the matrix of Camera3D::Update
+    (Camera3D.cpp:51-98: rows (right.i, up.i, forward.i, pos.i)) is rebuilt in float64 from the fp32 sines and
+    cosines, inverted by numpy.linalg.inv (LU, no shared code), and rtx_camera_params must agree to fp32
+    rounding over random poses; the projection scalars of Camera3D::Init (:8-48) likewise."""
+    R = U.pkg()
+    rng = np.random.default_rng(4242 + seed)
+    for _ in range(40):
+        pos = [float(np.float32(v)) for v in rng.uniform(-500, 500, 3) * rng.choice([0.01, 1.0, 10.0])]
+        rot = [float(np.float32(rng.uniform(-1.55, 1.55))), float(np.float32(rng.uniform(-7, 7))), float(np.float32(rng.uniform(-1, 1)))]
+        w, h = int(rng.integers(1, 8000)), int(rng.integers(1, 4500))
+        p = R.camera_params(w, h, pos, rot)
+        f = np.float32
+        sp, cp, sy, cy = (np.float64(np.sin(f(rot[0]))), np.float64(np.cos(f(rot[0]))),
+                          np.float64(np.sin(f(rot[1]))), np.float64(np.cos(f(rot[1]))))
+        # fp32 products as the reference forms them, then everything else in float64
+        right = [cy, np.float64(f(-sp) * f(sy)), np.float64(f(-cp) * f(sy))]
+        up = [0.0, cp, -sp]
+        fwd = [-sy, np.float64(f(-sp) * f(cy)), np.float64(f(-cp) * f(cy))]
+        m = np.eye(4)
+        for i in range(3):
+            m[i] = [right[i], up[i], fwd[i], pos[i]]
+        want = np.linalg.inv(m)
+        got = np.array(p.inv_v[:], dtype=np.float64).reshape(4, 4)
+        # rotation block: entries are O(1); translation column: O(|pos|)
+        scale = np.ones((4, 4))
+        scale[:3, 3] = max(1.0, float(np.abs(pos).max()))
+        assert np.all(np.abs(got - want) <= 4e-6 * scale), (pos, rot, got - want)
+        assert np.allclose(got @ m, np.eye(4), atol=4e-6 * scale.max())
+        assert np.allclose(m @ got, np.eye(4), atol=4e-6 * scale.max())
+        assert list(p.cam_pos[:]) == pos and (p.x, p.y) == (w, h) and p.cam_far == 250.0
+        # Camera3D::Init: e = 1/tan(FOV/2), FOV = pi/1.5; aspect = w / (0.01 w h); element1 = e / aspect
+        e = 1.0 / np.tan((np.pi / 1.5) / 2.0)
+        assert abs(p.element2 - e) <= 2e-7 * e
+        assert abs(p.element1 - e * 0.01 * h) <= 1e-6 * e * 0.01 * h
+
+
+def test_camera_params_default_pose_is_the_surveys():
+    """default camera (pos 0, rot (0, pi, 0)): element1 = 0.866025388 at 400x150, element2 =
+    0.577350259, far 250, invV = [[-1,0,8.74228e-08,0],[0,1,0,0],[8.74228e-08,0,1,0],[0,0,0,1]] up to zero signs."""
+    R = U.pkg()
+    p = R.camera_params(400, 150)
+    assert np.float32(p.element1) == np.float32(0.866025388) and np.float32(p.element2) == np.float32(0.577350259)
+    inv = np.array(p.inv_v[:], dtype=np.float32).reshape(4, 4)
+    want = np.array([[-1, 0, 8.74228e-08, 0], [0, 1, 0, 0], [8.74228e-08, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    assert np.allclose(inv, want, rtol=1e-6, atol=1e-12)
+    assert np.float32(R.camera_params(1920, 1080).element1) == np.float32(6.2354) or abs(R.camera_params(1920, 1080).element1 - 6.2354) < 1e-4
+
+
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
 def test_synth_scene_matches_independent_numpy_generator(name):
     R = U.pkg()

@@ -22,9 +22,18 @@ N > 1: every frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H
        Total work is fixed as N grows ("strong").  Buffers are rings, so the exchange of a round overlaps
        the trace of the next; all K frames are complete inside the timed region.
 
-Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the fp32-VALU
-view, since the brute-force form of this path is VALU-bound) and "cpu_baseline" (the CPU oracle --
-a structure-faithful port of the reference's loop -- timed on this host's cores on one full frame).
+Timing (N = 1): after the run-in and the W warm-up steps, a batch of exactly K steps is timed with HIP events
+(recorded on the stream(s) the kernels are launched on: start event -> every render stream waits for it -> K
+steps -> the timing stream waits for every render stream -> stop event) and bracketed by synchronisation on both
+sides; the batch is repeated until at least --min-timed-ms of GPU time has been measured and the MEDIAN batch
+is reported ("timing" says how many repeats, their spread, and the wall-clock figure beside it).  The last frame
+of the last batch is then compared (SHA-256 of the whole 20*W*H buffer) with the committed golden value,
+outside the timed region: "verified_against_golden".
+
+Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the executed-VALU
+utilisation from the committed rocprofv3 counters, since this path is VALU-issue bound, not HBM bound) and
+"cpu_baseline" (the CPU oracle -- a structure-faithful port of the reference's loop -- timed on this host's
+cores on full frames of the same workload).
 """
 import argparse
 import importlib
@@ -41,6 +50,24 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 BASELINE_METRIC = "Mrays/s (primary rays) at 1920\u00d71080, 1024 spheres; 1/2/4/8 GPU"   # BASELINE.json "metric", verbatim
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak counts FMA as 2; this path may not contract, so 78.65 Tops/s
+VALU_PEAK_TLANEOPS = VALU_PEAK_TFLOPS / 2.0   # lane-operations per second when no instruction is an FMA
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
+def committed_counters(config, mode_name, kernel):
+    """Per-launch rocprofv3 PMC averages of this kernel from profiles/counters.json (written by
+    tools/make_counters.py from the committed *_summary.json of the same bench command); None when absent."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get("%s_%s_%s" % (config, mode_name, kernel))
+    except (OSError, ValueError):
+        return None
 
 
 def algorithmic_bytes(W, H, S, ns, npl, rows=None):
@@ -79,8 +106,11 @@ def main():
     ap.add_argument("--refine", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--verify", action="store_true", help="N=1: check the last frame against the golden hash (N>1 does so by default)")
-    ap.add_argument("--no-verify", action="store_true", help="N>1: skip the byte check of the last assembled frame")
+    ap.add_argument("--verify", action="store_true", help="(default) check the last frame against the golden hash, outside the timed region")
+    ap.add_argument("--no-verify", action="store_true", help="skip the byte check of the last frame")
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="N=1: the K-step batch is repeated until this much GPU time has been measured; the median batch is reported")
+    ap.add_argument("--max-repeats", type=int, default=2000)
     ap.add_argument("--root", default="rotate", choices=["rotate", "fixed"],
                     help="N>1: frame i is assembled on rank i %% N (rotate) or always on rank 0 (fixed)")
     ap.add_argument("--exchange", default="compact", choices=["compact", "rounds", "p2p"],
@@ -179,35 +209,78 @@ def main():
         # Clock ramp: an idle MI355X needs some tens of milliseconds of work to reach its running clocks (measured:
         # 25.3 us per frame when timing starts 5 ms after idle, 20.2 us in steady state).  So the GPU is first kept
         # busy with the same frames for --prewarm-ms; none of this is timed or counted.
+        def drain():
+            if args.what == "update-async":
+                while inflight:
+                    ctx.update_end(inflight.pop(0))
+            ctx.synchronize()
+            torch.cuda.synchronize()
+
         n_pre = 0
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
             for _ in range(64):
                 step(n_pre)
                 n_pre += 1
-            if args.what == "update-async":
-                while inflight:
-                    ctx.update_end(inflight.pop(0))
-            ctx.synchronize()
-            torch.cuda.synchronize()
+            drain()
         for i in range(Wm):
             step(i)
-        if args.what == "update-async":
-            while inflight:
-                ctx.update_end(inflight.pop(0))
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(K):
-            step(i)
-        if args.what == "update-async":
-            while inflight:
-                ctx.update_end(inflight.pop(0))
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        if args.verify:
-            torch.cuda.synchronize()
+        drain()
+
+        # One timed batch = exactly K steps, device-timed with HIP events on the streams the kernels run on and
+        # bracketed by synchronisation on both sides.
+        if args.what != "trace":
+            def timed_batch():       # the Update forms block on the host: wall clock is the measurement
+                t0 = time.perf_counter()
+                for i in range(K):
+                    step(i)
+                drain()
+                dt = (time.perf_counter() - t0) * 1e3
+                return dt, dt
+        elif F == 1:
+            def timed_batch():
+                t0 = time.perf_counter()
+                ctx.timer_start()                     # hipEventRecord on the context's stream
+                for i in range(K):
+                    step(i)
+                ev_ms = ctx.timer_stop()              # hipEventRecord + hipEventSynchronize + elapsed
+                torch.cuda.synchronize()
+                return ev_ms, (time.perf_counter() - t0) * 1e3
+        else:
+            tmain = torch.cuda.Stream()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            joins = [torch.cuda.Event() for _ in range(F)]
+
+            def timed_batch():
+                t0 = time.perf_counter()
+                ev0.record(tmain)
+                for st in streams:
+                    st.wait_event(ev0)                # no frame of the batch starts before the start event
+                for i in range(K):
+                    step(i)
+                for st, ev in zip(streams, joins):
+                    ev.record(st)
+                    tmain.wait_event(ev)              # the stop event follows the last frame of every stream
+                ev1.record(tmain)
+                ev1.synchronize()
+                torch.cuda.synchronize()
+                return ev0.elapsed_time(ev1), (time.perf_counter() - t0) * 1e3
+
+        ev_batches, wall_batches = [], []
+        while True:
+            e_ms, w_ms = timed_batch()
+            ev_batches.append(e_ms)
+            wall_batches.append(w_ms)
+            if len(ev_batches) >= args.max_repeats or (sum(ev_batches) >= args.min_timed_ms and len(ev_batches) >= 3):
+                break
+        batch_ms = median(ev_batches)
+        elapsed = batch_ms * 1e-3                     # seconds per K steps, the median batch
+        timing = {"method": "HIP events around each batch of K steps (fork/join over the render streams), sync on both sides; "
+                            "median over repeated batches" if args.what == "trace" else "wall clock around each batch of K blocking steps; median",
+                  "repeats": len(ev_batches), "timed_ms_total": round(sum(ev_batches), 3),
+                  "batch_ms": {"median": round(batch_ms, 5), "min": round(min(ev_batches), 5), "max": round(max(ev_batches), 5)},
+                  "wall_ms_per_step_median": round(median(wall_batches) / K, 5)}
+        if not args.no_verify and args.what == "trace":
             final = ctx.read_frame(frame_bytes) if F == 1 else fbufs[(K - 1) % F].cpu().numpy()
         else:
             final = None
@@ -220,10 +293,13 @@ def main():
             for _ in range(5):
                 ctx.render(params, mode)
             ctx.synchronize()
-            ctx.timer_start()
-            for _ in range(Kr):
-                ctx.render(params, mode)
-            kernel_ms = ctx.timer_stop() / Kr
+            singles = []
+            for _ in range(5):
+                ctx.timer_start()
+                for _ in range(Kr):
+                    ctx.render(params, mode)
+                singles.append(ctx.timer_stop() / Kr)
+            kernel_ms = median(singles)
     else:
         import torch.distributed as dist
         stream = torch.cuda.current_stream()
@@ -294,19 +370,24 @@ def main():
             slab0 = pipe.slabs[0] if pipe.slabs is not None else None
             exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
         final = None
+        timing = {"method": "wall clock around exactly K frames, barrier + synchronize on both sides, MAX over ranks", "repeats": 1}
         dist_verified = None
         if not args.no_verify:
             # byte check of the last assembled frame, outside the timed region: its root hashes it (SHA-256 of the
-            # whole 20*W*H buffer against the committed golden value) and the verdict is reduced to rank 0
-            ok = 1
+            # whole 20*W*H buffer against the committed golden value); the verdict is reduced to rank 0 as a
+            # tri-state: 1 = compared and equal, 0 = compared and different (or the check itself failed),
+            # 2 = no golden value for this config / mode, nothing compared
+            code = 2
             try:
                 if rank == pipe.root_of(last_frame):
-                    ok = int(_frame_matches_golden(pipe.frame(last_frame).cpu().numpy(), args.config, args.mode) is not False)
-            except Exception:   # a failed check must not lose the measurement
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    m = _frame_matches_golden(pipe.frame(last_frame).cpu().numpy(), args.config, args.mode)
+                    code = 2 if m is None else int(bool(m))
+            except Exception as exc:   # a failed check must not lose the measurement, but it must be seen
+                sys.stderr.write("bench.py: golden check of frame %d failed on rank %d: %r\n" % (last_frame, rank, exc))
+                code = 0
+            flag = torch.tensor([code], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            dist_verified = bool(flag.item())
+            dist_verified = {0: False, 1: True}.get(int(flag.item()))   # None: no rank compared anything
         # per-rank kernel time, measured apart from the pipeline, for the roofline object
         ctx.synchronize()
         ctx.timer_start()
@@ -338,31 +419,32 @@ def main():
         bytes_alg = algorithmic_bytes(W, H, 4 if (distributed and args.exchange == "compact") else S, ns, npl, my_rows)
         achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters of the committed profile of this same kernel
-        # (profiles/traffic.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none.
+        # (profiles/counters.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none.
         traffic = None
-        traffic_detail = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and my_rows == H:
-            try:
-                with open(tpath) as f:
-                    traffic_detail = json.load(f).get("%s_%s_%s" % (args.config, args.mode, ctx.last_kernel), None)
-                if traffic_detail:
-                    traffic = round(traffic_detail["total_bytes"])
-            except (OSError, ValueError, KeyError):
-                traffic = None
+        traffic_detail = committed_counters(args.config, args.mode, ctx.last_kernel) if my_rows == H else None
+        if traffic_detail and traffic_detail.get("total_bytes"):
+            traffic = round(traffic_detail["total_bytes"])
         flops = algorithmic_flops(W, H, ns, npl, hit_frac) * (my_rows / float(H))
+        # second view: this path is bound by VALU issue, not by HBM.  Executed utilisation from the committed
+        # rocprofv3 counters of this same kernel and workload: SQ_INSTS_VALU wave-instructions x 64 lanes per
+        # launch / kernel time / 78.65 T lane-ops/s (the fp32 vector peak with no FMA: -ffp-contract=off).
+        ctr = committed_counters(args.config, args.mode, ctx.last_kernel) if my_rows == H else None
+        valu = None
+        if ctr and ctr.get("SQ_INSTS_VALU"):
+            lane_ops = ctr["SQ_INSTS_VALU"] * 64.0
+            valu = {"executed_wave_instructions_per_launch": round(ctr["SQ_INSTS_VALU"]), "lane_ops_per_launch": lane_ops,
+                    "achieved": round(lane_ops / (kernel_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                    "frac": round(lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 5),
+                    "source": ctr.get("source"),
+                    "note": "executed VALU instructions (PMC) over the live kernel time; the reference's all-pairs loop would "
+                            "need %.3g flops per launch (SURVEY 8(d) formula), which the culling kernel provably does not have to do" % flops}
         roofline = {
             "bound": "hbm", "kernel": ctx.last_kernel, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
             "traffic_unit": "bytes per launch (compare with bytes_per_launch)", "traffic_source": (traffic_detail or {}).get("source"),
             "bytes_per_launch": bytes_alg, "kernel_ms": round(kernel_ms, 5),
-            "kernel_ms_note": "one launch at a time on one stream (HIP events), as in the rocprofv3 summaries under profiles/",
-            # second view: the brute-force form of this path is fp32-VALU bound, not HBM bound
-            "valu": {"flops_per_launch": flops, "achieved": round(flops / (kernel_ms * 1e-3) / 1e12, 3),
-                     "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(flops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 5),
-                     "note": "algorithmic flops of the reference's all-pairs loop (19/test); the binned kernel skips "
-                             "tests that provably miss, so its 'achieved' here can exceed what it executes"},
+            "kernel_ms_note": "one launch at a time on one stream (HIP events, median of 5 batches), as in the rocprofv3 summaries under profiles/",
+            "valu": valu,
         }
 
         cpu = None
@@ -400,7 +482,7 @@ def main():
                                    % (args.config, W, H, ns, npl, args.mode, seed),
                        "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel, "prewarm_ms": args.prewarm_ms,
                        "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs; %s" % (n_gpus, exchange_note)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "timing": timing, "roofline": roofline, "cpu_baseline": cpu,
         }
         if args.what != "trace":
             out["metric"] = "Mrays/s through the whole Update (trace + minimise + D2H of the minimised stream); not the graded metric"
@@ -413,8 +495,8 @@ def main():
                 "achieved": round(bytes_alg / (eff_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
                 "frac": round(bytes_alg / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "whole-job rate with overlapping launches; 'achieved'/'frac' above are for one launch alone"}
-        if verified is not None:
-            out["verified_against_golden"] = verified
+        # true / false = the last frame was compared with the committed golden SHA-256; null = nothing was compared
+        out["verified_against_golden"] = verified
         if cpu:
             out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
 

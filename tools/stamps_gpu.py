@@ -29,6 +29,8 @@ ctx.render(p, R.RGB_ASCII)
 ctx.synchronize()
 del os.environ["RTX_STAMPS_PTR"]
 s = buf.cpu().numpy().reshape(nwg, 16)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+np.save(os.path.join(ROOT, "gpurun_out", "stamps_sub%d.npy" % sub), s[:4096])   # raw, for offline analysis (row = linear block id)
 s = s[s[:, 0] != 0]
 n = s.shape[0]
 t0 = s[:, 0].min()

@@ -81,6 +81,11 @@ enum rtx_option {
     RTX_OPT_SUBTILES = 3,     /* sub-tiles per workgroup in the binned kernel (1, 2, 4, 8, 16); 0 = default */
     RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel: -1 auto (large scenes), 0 off, 1 on,
                                * 1 on (single pass), 2 on with the cells binned through blocks of 4x4 cells (auto does so from 16384 spheres) */
+    RTX_OPT_TILE_ORDER = 6,   /* binned kernel: dispatch the macro tiles heaviest first, from the work estimates the previous frames
+                               * of the same tile grid left behind (speed only: the frame is the same in any order).  0 = frame
+                               * order (default: measured gain 1.5 % for one 1080p launch alone, none with frames in flight, and a
+                               * 10 % loss at 8K, where it scatters the record writes); k > 0 = derive the order after the first
+                               * two frames of a grid, then after every k-th */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup; otherwise it stays off) */
 };

@@ -57,6 +57,22 @@ struct rtx_ctx {
     };
     std::vector<CellScratch> cell_scratch;
 
+    // heaviest-first dispatch order of the macro tiles, one set per render stream (everything that touches a set
+    // is queued on that one stream, in order: trace writes the estimates, rtx_order_tiles turns them into the
+    // order the following traces read).  `key` identifies the tile grid the buffers describe.
+    struct TileOrder {
+        hipStream_t stream = nullptr;
+        uint32_t* cost = nullptr;
+        uint32_t* order = nullptr;
+        size_t cap = 0;              // tiles the buffers hold
+        uint64_t key[3] = {0, 0, 0};
+        bool have_order = false;
+        uint64_t frames = 0;         // traces of this grid since the last reset
+    };
+    std::vector<TileOrder> tile_orders;
+    int64_t opt_tile_order = 0;     // 0 = off (default); k = re-derive the order after the 1st and 2nd frame of a grid, then every k-th
+    int n_cu = 0;                   // compute units of the device
+
     // events of rtx_submit_slabs' fork/join: one for `after`, one per distinct render stream seen
     hipEvent_t ev_fork = nullptr;
     struct JoinEvent {

@@ -50,6 +50,12 @@ struct KArgs {
     const uint32_t* bin_in_list;
     const uint32_t* bin_in_count;
     uint32_t bin_in_shift, bin_in_px;  // bin_in_px: parent cells per row
+    // Heaviest-first dispatch (speed only; any permutation of the macro tiles renders the same frame): tile_order[b] =
+    // bx | by << 16 of the macro tile that workgroup b (linear block index, x fastest) renders, built by
+    // rtx_order_tiles from tile_cost, the work estimate every workgroup of an earlier launch left for its tile.
+    // Either may be nullptr (identity order / no estimate wanted).
+    const uint32_t* tile_order;
+    uint32_t* tile_cost;
     uint8_t* out;             // records of row out_row_base start here
     uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;
@@ -81,4 +87,7 @@ int rtx_k_launch_expand(const ExpandArgs* e, int mode, unsigned blocks, void* st
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
 int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
+// tile_cost[n_tiles] (grid gx wide) -> tile_order[n_tiles], heaviest first, dealt over n_cu compute units so that the
+// workgroups each unit receives in the first dispatch round (blocks c, c + n_cu, c + 2 n_cu, ...) carry equal work.
+int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round, uint32_t* tile_order, void* stream);
 }

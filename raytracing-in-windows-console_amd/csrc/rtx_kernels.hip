@@ -17,6 +17,8 @@
 #include "rtx_device.hpp"
 #include "rtx_kernels.h"
 
+#include <cstdlib>
+
 namespace rtx {
 
 // Timing experiments only (make ablate -> librtx_hip_ablate.so, never shipped): ABL(bit) is true when
@@ -26,7 +28,7 @@ namespace rtx {
 // wave 0 of each workgroup stamps the shader clock into its slot of a.stamps (diagnostic build only)
 #define STAMP(i)                                                                                            \
     do {                                                                                                    \
-        if (a.stamps && threadIdx.x == 0) {                                                                 \
+        if (a.stamps && threadIdx.x == 0 && !(a.ablate & 0x8000u)) { /* 0x8000: start/end stamps only */     \
             unsigned long long t__;                                                                         \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
             a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t__;                         \
@@ -49,26 +51,23 @@ constexpr int kListCapCull = 704;    // culling kernels: room for one more 512-s
 constexpr float kNoHit = 99999999.f; // RayTracing.h:21
 
 // RayTracing.h:97-115 (68 glyphs).
-__constant__ const char kRamp[68] = {
+__constant__ __attribute__((aligned(4))) const char kRamp[68] = {
     ' ', '.', '`', '^', '"', ',', ':', ';', 'I', 'l', '!', 'i', '>', '<', '~', '+', '_',
     '-', '?', '*', ']', '[', '}', '{', '1', ')', '(', '|', '/', 't', 'f', 'j', 'r', 'x',
     'n', 'u', 'v', 'c', 'z', 'm', 'w', 'X', 'Y', 'U', 'J', 'C', 'L', 'q', 'p', 'd', 'b',
     'k', 'h', 'a', 'o', '#', '%', 'Z', 'O', '8', 'B', '$', '0', 'Q', 'M', '&', 'W', '@'
 };
 
-// Three decimal digits of 0..255, NUL padded (RayTracing.cu:212-229): d0 | d1 << 8 | d2 << 16, built at compile time.
-struct DigitsTable {
-    uint32_t v[256];
-    constexpr DigitsTable() : v()
-    {
-        for (uint32_t i = 0; i < 256u; i++) {
-            const uint32_t d0 = i >= 100u ? 48u + i / 100u : 0u;
-            const uint32_t d1 = i >= 10u ? 48u + (i / 10u) % 10u : 0u;
-            v[i] = d0 | (d1 << 8) | ((48u + i % 10u) << 16);
-        }
-    }
-};
-__constant__ const DigitsTable kDigits = DigitsTable();
+// Three decimal digits of i = 0..255, NUL padded (RayTracing.cu:212-229): d0 | d1 << 8 | d2 << 16.  Computed, not
+// loaded: every workgroup fills its LDS table from this at start-up, and a dozen integer instructions are cheaper
+// than a round trip to memory at the head of the kernel.
+__host__ __device__ constexpr uint32_t digits_word(uint32_t i)
+{
+    const uint32_t h = i / 100u, r = i - 100u * h, t = r / 10u, u = r - 10u * t;
+    return (i >= 100u ? 48u + h : 0u) | ((i >= 10u ? 48u + t : 0u) << 8) | ((48u + u) << 16);
+}
+static_assert(digits_word(0) == 0x300000u && digits_word(7) == 0x370000u && digits_word(42) == 0x323400u &&
+              digits_word(100) == 0x303031u && digits_word(255) == 0x353532u, "digit encoder");
 
 // Conservative inflation of a sphere for culling.  A ray whose fp32 test reports a hit passes, in exact
 // arithmetic, within R of the centre with R^2 = r^2 (1+2u) + 15.2u |otc|^2 (u = 2^-24; derivation in
@@ -357,6 +356,11 @@ __device__ __forceinline__ Ray ray_from_tables(const Camera& c, float4 A, float4
     return r;
 }
 
+// Work estimate of one wave's pass over one sub-tile, in VALU instructions (tools/ablate_pmc_gpu.sh: about 100 for
+// ray generation, planes and a miss record; 3 per candidate rejected; 330 more when anything is hit: the hit tests'
+// slow path, the winner's normal, shading and the record).  Only the order of the sums matters.
+constexpr uint32_t kCostPass = 100u, kCostCandidate = 3u, kCostShaded = 330u;
+
 constexpr int kMaxMacro = 128;    // macro tile is at most 128 x 128 pixels
 constexpr int kChunk = 2 * kThreads; // spheres staged per barrier: two per thread
 constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes take the direct path
@@ -365,6 +369,8 @@ constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes tak
 // are this thread's geometry records, already loaded: the caller prefetches the next step's first.  Hoists the
 // ray-independent terms, culls, and appends survivors to the LDS list in index order (wave ballots,
 // per-wave counts through LDS, one barrier).  Returns the new list length (uniform).
+// (Keeping the geometry and colour records of the first list entries in LDS, so that a pass takes its winner's records
+// from there instead of a round trip to memory, was measured and dropped: no gain, profiles/r02_c_single_launch_experiments.md.)
 template <bool CULL>
 __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
                                                 uint32_t k0, uint32_t k1, float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8],
@@ -375,6 +381,7 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
     float4 rec[2];
     float mg[2] = {0.0f, 0.0f};
     const float4 g[2] = {g0, g1};
+
     // the second half of the step is empty when at most 256 items are left (short cell lists, the tail of a scene):
     // skip its arithmetic (uniform branch)
     const bool second_half_empty = base + (uint32_t)kThreads >= ns;
@@ -478,12 +485,13 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ float4 s_row[kMaxMacro];          // per row:    (m1, m5, m9) * vy
     __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
     __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
-    __shared__ uint8_t s_ramp[68];               // the glyph ramp (RayTracing.h:97-115)
+    __shared__ __attribute__((aligned(4))) uint8_t s_ramp[68]; // the glyph ramp (RayTracing.h:97-115)
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
     __shared__ float s_frustum[16];              // the macro tile's five plane normals
     __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
     __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
+    __shared__ uint32_t s_cost[2];               // this tile's work estimate, summed over the waves; waves done
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
@@ -492,9 +500,15 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     const uint32_t nsub = a.nsub;
     const uint32_t nx = 1u << lnx, ny = nsub >> lnx;
     const uint32_t mw = tw * nx, mh = th * ny;   // macro tile, pixels
-    const uint32_t mcol0 = blockIdx.x * mw;
-    const uint32_t mrow0 = a.row0 + blockIdx.y * mh;
-    const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
+    // which macro tile: this workgroup's own position in the grid, or what the heaviest-first order assigns to it
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
+    if (a.tile_order != nullptr) {
+        const uint32_t packed = a.tile_order[blockIdx.y * gridDim.x + blockIdx.x];
+        bx = packed & 0xffffu;
+        by = packed >> 16;
+    }
+    const uint32_t mcol0 = bx * mw;
+    const uint32_t mrow0 = a.row0 + by * mh;
 
     Camera cam;
 #pragma unroll
@@ -523,7 +537,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     items.list = nullptr;
     items.count = a.ns;
     if (CULL && a.cell_list != nullptr) {
-        const uint32_t cell = (blockIdx.y >> a.cell_log2gy) * a.cells_x + (blockIdx.x >> a.cell_log2gx);
+        const uint32_t cell = (by >> a.cell_log2gy) * a.cells_x + (bx >> a.cell_log2gx);
         items.list = a.cell_list + (size_t)cell * a.ns;
         items.count = a.cell_count[cell];
     }
@@ -534,9 +548,16 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     float4 g0 = load_item(items, tid, k0), g1 = load_item(items, kThreads + tid, k1);
 
     // ---- per-workgroup tables (visible after the first barrier below)
-    s_digits[tid] = kDigits.v[tid];
-    if (tid < 68u) {
-        s_ramp[tid] = (uint8_t)kRamp[tid];
+    s_digits[tid] = digits_word(tid);
+    // the glyph ramp is requested now and written to LDS after the staging loop (first read: encode), so that no
+    // wave waits for it here
+    uint32_t ramp4 = 0u;
+    if (tid < 17u) {
+        ramp4 = reinterpret_cast<const uint32_t*>(kRamp)[tid];
+    }
+    if (tid == 0u) {
+        s_cost[0] = 0u;
+        s_cost[1] = 0u;
     }
     if (tid < mw) {
         // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
@@ -613,6 +634,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         }
         total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u), REFINE ? s_margin : nullptr);
     }
+    if (tid < 17u) {
+        reinterpret_cast<uint32_t*>(s_ramp)[tid] = ramp4;
+    }
     if (tid < np_tab) {
         // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
         const V3 p = v3(pla.x, pla.y, pla.z), n = v3(plb.x, plb.y, plb.z);
@@ -625,7 +649,11 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     lds_barrier(); // list complete, tables visible
     STAMP(2);
 
-    // ---- one pass per sub-tile
+    // ---- one pass per sub-tile.  (Drawing the waves' 64-pixel shares of the sub-tiles from a counter in LDS, so that a
+    // wave whose pixels miss everything moves on while its neighbour shades, was measured and dropped: +6 % per frame --
+    // profiles/r02_c_single_launch_experiments.md.)
+    uint32_t wcost = 0; // this wave's work estimate for the heaviest-first order (wave-uniform)
+    const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
 #pragma unroll 1
     for (uint32_t j = 0; j < nsub; j++) {
         const uint32_t jx = j & (nx - 1u), jy = j >> lnx;
@@ -641,6 +669,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         Best b;
         b.t = kNoHit;
         b.k = 0xffffffffu;
+        uint32_t scanned = overflow ? ns : total; // candidates this wave tests in this pass
         if (!overflow) {
             bool refined = false;
             if (REFINE && total > 8u) {
@@ -674,6 +703,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 cnt = __builtin_amdgcn_readfirstlane(cnt);
                 if (cnt <= (uint32_t)kWaveListCap) {
                     refined = true;
+                    scanned = cnt + (total >> 4); // its own candidates, and the refinement's share
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
                     for (uint32_t q = 0; q < cnt; q++) {
                         const uint32_t i = s_wlist[wave][q];
@@ -761,7 +791,15 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         } else if (plane_q != 0xffffffffu || b.k != 0xffffffffu) {
             V3 n0, od;
             if (plane_q != 0xffffffffu) {
-                const float4 pb = a.pl_b[plane_q], pd = a.pl_od[plane_q];
+                // the plane's normal and colour: from the LDS table when it is there (the same values)
+                float4 pb, pd;
+                if (plane_q < np_tab) {
+                    pb = s_plane[3u * plane_q + 0u];
+                    pd = s_plane[3u * plane_q + 2u];
+                } else {
+                    pb = a.pl_b[plane_q];
+                    pd = a.pl_od[plane_q];
+                }
                 n0 = v3(pb.x, pb.y, pb.z);
                 od = v3(pd.x, pd.y, pd.z);
             } else {
@@ -780,14 +818,27 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         if (MODE != RTX_K_SDL && !ABL(64u)) {
             encode_and_store<MODE, OUT>(a, cam, s_digits, s_ramp, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
         }
+        // per wave and pass: ray generation, planes and encoding; the exact test per candidate; winner normal, shading
+        // and the hit tests' slow path when the wave sees anything (instruction counts of tools/ablate_pmc_gpu.sh)
+        wcost += kCostPass + kCostCandidate * scanned + (__ballot(in_frame && distance <= cam.far) != 0ull ? kCostShaded : 0u);
         STAMP(3 + (j < 9u ? j : 9u));
 #ifdef RTX_ABLATE
         if (a.stamps && threadIdx.x == 0) {
             unsigned long long rt;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
             a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 13] = rt; // end of the latest pass
+            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 12] = ((unsigned long long)total << 32) | wcost;
         }
 #endif
+    }
+    // ---- leave this tile's work estimate for rtx_order_tiles: the sum over the four waves, stored by the last one
+    // to get here (LDS atomics of one wave execute in order, so the fourth increment sees all four sums)
+    // (lane number from mbcnt: keeping tid & 63 alive across the whole kernel for this one test costs a register)
+    if (a.tile_cost != nullptr && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+        atomicAdd(&s_cost[0], (uint32_t)__builtin_amdgcn_readfirstlane(wcost));
+        if (atomicAdd(&s_cost[1], 1u) == (uint32_t)(kThreads / 64 - 1)) {
+            a.tile_cost[by * gridDim.x + bx] = *reinterpret_cast<volatile uint32_t*>(&s_cost[0]);
+        }
     }
 }
 
@@ -943,6 +994,86 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
     }
 }
 
+// rtx_order_tiles: the dispatch order of the next launches' macro tiles from the work estimates the workgroups of
+// an earlier launch left in tile_cost.  One workgroup; a counting sort over 1024 cost classes (heaviest class first;
+// the order within a class is whatever the atomics give -- any permutation renders the same frame, so only speed
+// depends on it, and every tile receives exactly one rank by construction whatever tile_cost holds).
+//
+// Why order at all: a launch's workgroups all become resident at once (7 per CU: 1792 of C2's 2040), block b on CU
+// b mod n_cu (observed: round-robin; nothing depends on it but speed), and finish when their CU has worked through
+// whatever it was dealt.  In frame order the tiles of a CU differ by 3x in work and the expensive rows come last:
+// the slowest CU takes a third longer than the average and the second-round workgroups start late and run long
+// (profiles/r02_b_stamps_sub4.txt).  So: the tiles go out heaviest first, the first `first_round` of them dealt
+// boustrophedon over the CUs (round k ascending for even k, descending for odd k) so that every CU's share
+// carries the same work, and the light remainder fills the slots as they free up.
+constexpr int kOrderThreads = 1024, kOrderBins = 1024;
+
+__global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t* __restrict__ cost, uint32_t n, uint32_t gx, uint32_t n_cu,
+                                                                  uint32_t first_round, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_hist[kOrderBins];
+    __shared__ uint32_t s_lo[kOrderThreads / 64], s_hi[kOrderThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        const uint32_t c = cost[i];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (lane == 0u) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+    }
+    s_hist[tid] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOrderThreads / 64; k++) {
+        lo = s_lo[k] < lo ? s_lo[k] : lo;
+        hi = s_hi[k] > hi ? s_hi[k] : hi;
+    }
+    const uint64_t range = (uint64_t)(hi - lo) + 1u;
+    auto bin_of = [&](uint32_t c) { return (uint32_t)(((uint64_t)(hi - c) * (uint64_t)kOrderBins) / range); }; // 0 = heaviest
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        atomicAdd(&s_hist[bin_of(cost[i])], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix sum over the classes (one per thread): wave scan, then the waves' totals
+    const uint32_t mine = s_hist[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= (uint32_t)d) incl += o;
+    }
+    __syncthreads();
+    if (lane == 63u) s_lo[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+#pragma unroll
+    for (int k = 0; k < kOrderThreads / 64; k++) {
+        before += (uint32_t)k < wave ? s_lo[k] : 0u;
+    }
+    s_hist[tid] = before + incl - mine; // now: next free rank of the class
+    __syncthreads();
+    const uint32_t rounds = n_cu ? first_round / n_cu : 0u; // whole rounds dealt boustrophedon
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        const uint32_t rank = atomicAdd(&s_hist[bin_of(cost[i])], 1u);
+        uint32_t blk = rank;
+        if (n_cu && rank < rounds * n_cu) {
+            const uint32_t k = rank / n_cu, c = rank - k * n_cu;
+            blk = (k & 1u) ? k * n_cu + (n_cu - 1u - c) : rank;
+        }
+        const uint32_t by = i / gx, bx = i - by * gx;
+        order[blk] = bx | (by << 16);
+    }
+}
+
 // rtx_expand: compact pixel words -> records, for up to kMaxExpandSeg segments (a segment = a run of pixels that
 // is contiguous in both buffers: one rank's rows of one frame).  Pure streaming: 4 bytes read, S written per pixel.
 // A workgroup takes kExpandPixels consecutive pixels of one segment, 256 at a time; each wave transposes the
@@ -956,7 +1087,7 @@ __global__ __launch_bounds__(kThreads) void rtx_expand_words(const ExpandArgs e)
     __shared__ uint32_t s_digits[256];
     __shared__ __attribute__((aligned(16))) uint32_t s_rec[kThreads * SW];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    s_digits[tid] = kDigits.v[tid];
+    s_digits[tid] = digits_word(tid);
     uint32_t k = 0;
     while (k + 1u < e.nseg && blockIdx.x >= e.first_block[k + 1u]) {
         k++;
@@ -1048,13 +1179,17 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
+    unsigned lds_pad = 0; // experiment builds: extra dynamic LDS per workgroup, to cap the workgroups a CU holds
+#ifdef RTX_ABLATE
+    if (const char* e = getenv("RTX_LDS_PAD")) lds_pad = (unsigned)strtoul(e, nullptr, 0);
+#endif
 #define RTX_LAUNCH(M, C, O, SUFFIX)                                                          \
     do {                                                                                     \
         if (C && a->refine) {                                                                \
-            hipLaunchKernelGGL((rtx_trace<M, C, O, C>), grid, block, 0, stream, *a);         \
+            hipLaunchKernelGGL((rtx_trace<M, C, O, C>), grid, block, lds_pad, stream, *a);   \
             name = "rtx_trace<" #M "," #C SUFFIX ",refine>";                                 \
         } else {                                                                             \
-            hipLaunchKernelGGL((rtx_trace<M, C, O, false>), grid, block, 0, stream, *a);     \
+            hipLaunchKernelGGL((rtx_trace<M, C, O, false>), grid, block, lds_pad, stream, *a); \
             name = "rtx_trace<" #M "," #C SUFFIX ">";                                        \
         }                                                                                    \
     } while (0)
@@ -1102,6 +1237,17 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
 extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream_v)
 {
     hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(cells_x, cells_y, splits), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round,
+                                        uint32_t* tile_order, void* stream_v)
+{
+    if (n_tiles == 0 || gx == 0 || gx > 0xffffu || (n_tiles + gx - 1u) / gx > 0xffffu) {
+        return (int)hipErrorInvalidValue;
+    }
+    if (first_round > n_tiles) first_round = n_tiles;
+    hipLaunchKernelGGL(rtx::rtx_order_tiles, dim3(1), dim3(rtx::kOrderThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, first_round, tile_order);
     return (int)hipGetLastError();
 }
 

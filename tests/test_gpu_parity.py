@@ -39,7 +39,9 @@ def assert_same(got, want, mode, W, what):
 KERNELS = ["brute", "binned"]
 
 
-def set_kernel(R, ctx, kernel, tile=0, subtiles=0, two_level=-1, refine=-1):
+def set_kernel(R, ctx, kernel, tile=0, subtiles=0, two_level=-1, refine=-1, tile_order=None):
+    if tile_order is not None:
+        ctx.set_option(R.OPT_TILE_ORDER, tile_order)
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, tile)
     ctx.set_option(R.OPT_SUBTILES, subtiles)
@@ -493,3 +495,63 @@ def test_refinement_with_more_survivors_than_a_wave_keeps(R, ctx):
         got = ctx.render_to_host(p, R.RGB_ASCII)
         assert_same(got, want, O.RGB_ASCII, 192, "refine overflow sub %d" % sub)
     set_kernel(R, ctx, "auto")
+
+
+# ---------------------------------------------------------------- heaviest-first dispatch order (RTX_OPT_TILE_ORDER)
+
+def _render_into_poisoned_buffer(R, ctx, p, mode, buf):
+    """Whole frame into a caller buffer that starts as 0xEE everywhere: a macro tile that no workgroup renders (an
+    order that is not a permutation) leaves its bytes poisoned."""
+    import torch
+    buf.fill_(0xEE)
+    torch.cuda.synchronize()
+    ctx.render_rows(p, mode, 0, int(p.y), d_out=buf.data_ptr(), out_row_base=0)
+    ctx.synchronize()
+    return buf.cpu().numpy()
+
+
+@pytest.mark.parametrize("period", [1, 3])
+def test_tile_order_keeps_every_frame_identical(R, ctx, period):
+    """The order the workgroups take the macro tiles in is derived from the previous frames' work estimates; any
+    permutation must give the same bytes.  C2 over several frames (order refreshed after every frame / every third),
+    every frame against the golden hash."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+    gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+    set_kernel(R, ctx, "binned", tile_order=period)
+    for i in range(7):
+        assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold, "frame %d" % i
+    set_kernel(R, ctx, "binned", tile_order=0)
+    assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold
+    set_kernel(R, ctx, "auto", tile_order=16)
+
+
+def test_tile_order_with_a_moving_camera_changing_grids_and_slabs(R, ctx):
+    """Stale estimates (the camera moves every frame), a different tile grid every few frames (frame size, sub-tile
+    count, two-level culling on and off) and row slabs: always the frame the brute kernel renders in frame order."""
+    import torch
+    rng = np.random.default_rng(77)
+    sph, pl = R.synth_scene(9, 900, 2, 6.0, 0.577)
+    ctx.set_scene(sph, pl)
+    buf = torch.empty(20 * 1920 * 1080, dtype=torch.uint8, device="cuda")
+    for step in range(14):
+        w, h = [(1920, 1080), (1283, 721), (1920, 1080), (960, 1080)][(step // 3) % 4]
+        pos = [float(v) for v in rng.uniform(-3, 3, 3)]
+        rot = (float(rng.uniform(-0.2, 0.2)), float(np.pi + rng.uniform(-0.3, 0.3)), 0.0)
+        p = R.camera_params(w, h, pos, rot)
+        set_kernel(R, ctx, "brute", tile_order=0)
+        want = ctx.render_to_host(p, R.RGB_ASCII)
+        set_kernel(R, ctx, "binned", subtiles=(0, 2, 8)[step % 3], two_level=(0, 1)[(step // 2) % 2], tile_order=1)
+        got = _render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)[:20 * w * h]
+        assert_same(got, want, R.RGB_ASCII, w, "tile order, moving camera, step %d" % step)
+        # the same frame again as three ragged slabs (each slab shape has its own tile grid and order)
+        buf.fill_(0xEE)
+        torch.cuda.synchronize()
+        for r0, r1 in ((0, h // 3), (h // 3, h // 2 + 5), (h // 2 + 5, h)):
+            ctx.render_rows(p, R.RGB_ASCII, r0, r1 - r0, d_out=buf.data_ptr(), out_row_base=0)
+        ctx.synchronize()
+        assert_same(buf.cpu().numpy()[:20 * w * h], want, R.RGB_ASCII, w, "tile order, slabs, step %d" % step)
+    set_kernel(R, ctx, "auto", tile_order=16)

@@ -79,8 +79,11 @@ enum rtx_option {
     RTX_OPT_KERNEL = 1,       /* enum rtx_kernel */
     RTX_OPT_TILE_LOG2_W = 2,  /* log2 of the sub-tile width in pixels (2..6; a sub-tile is 256 pixels); 0 = choose from the camera */
     RTX_OPT_SUBTILES = 3,     /* sub-tiles per workgroup in the binned kernel (1, 2, 4, 8, 16); 0 = default */
-    RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel: -1 auto (large scenes), 0 off, 1 on,
-                               * 1 on (single pass), 2 on with the cells binned through blocks of 4x4 cells (auto does so from 16384 spheres) */
+    RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel (one launch: blocks of 4x4 cells, then the cells):
+                               * -1 auto (from 2048 spheres), 0 off, 1 on (2 is accepted and means 1) */
+    RTX_OPT_CELL_CAPACITY = 7, /* entries per coarse-cell list of that pre-pass; 0 = auto (4 * spheres / cells + 1024, so that the
+                               * scratch is O(spheres)).  A cell whose list does not fit falls back to the whole scene: slower,
+                               * the same frame */
     RTX_OPT_TILE_ORDER = 6,   /* binned kernel: dispatch the macro tiles heaviest first, from the work estimates the previous frames
                                * of the same tile grid left behind (speed only: the frame is the same in any order).  0 = frame
                                * order (default: measured gain 1.5 % for one 1080p launch alone, none with frames in flight, and a

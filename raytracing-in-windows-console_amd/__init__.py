@@ -24,7 +24,7 @@ SIZE_8BIT, SIZE_RGB = 12, 20
 
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_TOO_LARGE = range(7)
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
-OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER = 1, 2, 3, 4, 5, 6
+OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY = 1, 2, 3, 4, 5, 6, 7
 RENDER_ZERO_TAIL = 1
 RENDER_COMPACT = 2
 RENDER_VALUES = 4

@@ -45,15 +45,16 @@ struct rtx_ctx {
     int64_t opt_subtiles = 0;
     int64_t opt_two_level = -1;     // -1 auto, 0 off, 1 on
     int64_t opt_refine = -1;        // -1 auto, 0 off, 1 on
+    int64_t opt_cell_capacity = 0;  // entries per coarse cell list; 0 = 4 ns / cells + 1024
     // two-level culling scratch, one set per stream that renders (launches on one stream are ordered, so a
     // set is never shared by frames in flight on different streams)
     struct CellScratch {
         hipStream_t stream = nullptr;
-        uint32_t* list = nullptr;
-        uint32_t* count = nullptr;
-        size_t list_words = 0, count_words = 0;   // count holds the cells' counters, then the parent cells' (one memset)
-        uint32_t* parent_list = nullptr;          // hierarchical binning (very large scenes): lists of the 4x4-cell blocks
-        size_t parent_words = 0;
+        uint32_t* list = nullptr;                 // cells x capacity sphere indices
+        uint32_t* count = nullptr;                // two alternating buffers of one counter per cell
+        size_t list_words = 0, count_words = 0;
+        uint32_t n_cells = 0;                     // the cell grid the counters were last zeroed for
+        uint32_t flip = 0;                        // which counter buffer the next launch accumulates into
     };
     std::vector<CellScratch> cell_scratch;
 

@@ -37,19 +37,17 @@ struct KArgs {
     const float4* pl_b;       // nx ny nz height
     const float4* pl_od;      // R/255 G/255 B/255 gidx
     const uint8_t* grey;      // 256-byte grey lookup of the xterm-256 mapper
-    // Two-level culling (large scenes): per coarse cell, sphere indices (stride ns, any order) and their count.
+    // Two-level culling (large scenes): per coarse cell a list of sphere indices (cell_cap entries apart, any order) and
+    // its count; a count above cell_cap means the list did not fit and the cell's workgroups stage the whole scene.
     // cell_list == nullptr: every workgroup stages the whole scene.
     const uint32_t* cell_list;
     const uint32_t* cell_count;
-    uint32_t* cell_list_out;  // rtx_bin_cells writes these two
+    uint32_t* cell_list_out;  // rtx_bin_cells writes these two ...
     uint32_t* cell_count_out;
+    uint32_t* cell_count_zero; // ... and zeroes this one (the other counter buffer, for the next launch on the stream)
     uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
-    uint32_t cells_x;
-    // rtx_bin_cells input: every sphere (bin_in_list == nullptr), or the list of the parent cell -- a block of
-    // 2^bin_in_shift x 2^bin_in_shift cells binned by a previous, coarser rtx_bin_cells launch (stride ns, like cell_list)
-    const uint32_t* bin_in_list;
-    const uint32_t* bin_in_count;
-    uint32_t bin_in_shift, bin_in_px;  // bin_in_px: parent cells per row
+    uint32_t cells_x, cells_y;
+    uint32_t cell_cap;        // entries per cell list
     // Heaviest-first dispatch (speed only; any permutation of the macro tiles renders the same frame): tile_order[b] =
     // bx | by << 16 of the macro tile that workgroup b (linear block index, x fastest) renders, built by
     // rtx_order_tiles from tile_cost, the work estimate every workgroup of an earlier launch left for its tile.
@@ -85,7 +83,7 @@ int rtx_k_launch_expand(const ExpandArgs* e, int mode, unsigned blocks, void* st
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
-int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream);
+int rtx_k_launch_bin_cells(const KArgs* a, unsigned splits, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 // tile_cost[n_tiles] (grid gx wide) -> tile_order[n_tiles], heaviest first, dealt over n_cu compute units so that the
 // workgroups each unit receives in the first dispatch round (blocks c, c + n_cu, c + 2 n_cu, ...) carry equal work.

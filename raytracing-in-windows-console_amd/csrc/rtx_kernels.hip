@@ -93,43 +93,6 @@ __device__ __forceinline__ V3 view_dir(const Camera& c, float cx, float cy)
     return v3(c.m[0] * vx + c.m[1] * vy + c.m[2], c.m[4] * vx + c.m[5] * vy + c.m[6], c.m[8] * vx + c.m[9] * vy + c.m[10]);
 }
 
-// Side planes of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows
-// [row0, row0+h), grown by half a pixel on every side.  Pixel directions are linear in (cx, cy), so
-// every pixel ray of the tile lies in the convex cone of the four corner directions.  A normal
-// that cannot be oriented (degenerate matrix, NaN) becomes the zero vector, which never culls.
-// This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the
-// slack in tile_culls covers their error.
-__device__ __forceinline__ TileFrustum tile_frustum(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h)
-{
-    const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
-    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
-    const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
-    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;       // top edge (larger cy)
-    const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;  // bottom edge
-    const V3 c00 = view_dir(c, x0, y0), c10 = view_dir(c, x1, y0), c11 = view_dir(c, x1, y1), c01 = view_dir(c, x0, y1);
-    const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
-    V3 raw[4] = {cross(c00, c10), cross(c10, c11), cross(c11, c01), cross(c01, c00)};
-    TileFrustum f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        V3 n = raw[k];
-        float side = dot(n, axis);
-        if (!(side > 0.0f)) {
-            n = mulf(n, -1.0f);
-            side = -side;
-        }
-        const float len2 = dot(n, n);
-        if (side > 0.0f && len2 > 1.0e-30f && len2 < 1.0e30f) {
-            f.n[k] = mulf(n, __builtin_amdgcn_rsqf(len2));
-        } else {
-            f.n[k] = v3(0.0f, 0.0f, 0.0f);
-        }
-    }
-    const float alen2 = dot(axis, axis);
-    f.n[4] = (alen2 > 1.0e-30f && alen2 < 1.0e30f) ? mulf(axis, __builtin_amdgcn_rsqf(alen2)) : v3(0.0f, 0.0f, 0.0f);
-    return f;
-}
-
 // true when the sphere (hoisted form) provably cannot be hit by any pixel ray of the tile.
 __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float oy, float oz, float oo, float r, float& margin)
 {
@@ -145,9 +108,13 @@ __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float
     return out;
 }
 
-// One plane of the same pyramid, selected by k: 0..3 the side through corners k and k+1 (corner order
-// (x0,y0) (x1,y0) (x1,y1) (x0,y1)), 4 the axis plane.  Same arithmetic as tile_frustum, arranged so that five
-// lanes can compute the five planes side by side.
+// One plane of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows [row0, row0+h), grown by
+// half a pixel on every side, selected by k: 0..3 the side through corners k and k+1 (corner order (x0,y0) (x1,y0)
+// (x1,y1) (x0,y1)), 4 the axis plane -- arranged so that five lanes compute the five planes side by side.  Pixel
+// directions are linear in (cx, cy), so every pixel ray of the rectangle lies in the convex cone of the four corner
+// directions.  A normal that cannot be oriented (degenerate matrix, NaN) becomes the zero vector, which never
+// culls.  This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the slack in
+// tile_culls covers their error.
 __device__ __forceinline__ V3 tile_plane(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, uint32_t k)
 {
     const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
@@ -161,6 +128,17 @@ __device__ __forceinline__ V3 tile_plane(const Camera& c, uint32_t col0, uint32_
     const V3 va = view_dir(c, xa, ya), vb = view_dir(c, xb, yb);
     const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
     V3 n = k < 4u ? cross(va, vb) : axis;
+    if (k == 4u) {
+        // The axis plane (it culls what lies behind the apex) is only a bound while every ray of the pyramid points
+        // into its front half-space, i.e. while all four corner directions do: a wide rectangle that straddles the
+        // view axis off-centre (a block of cells hanging over the frame's edge, a tile of a 5-pixel-wide frame) has
+        // corner rays more than 90 degrees from its own axis.  Then the plane is dropped (zero normal: never culls).
+        const V3 vc = view_dir(c, x1, y1), vd = view_dir(c, x0, y1); // va, vb are corners 0 and 1 here
+        const float lo = fminf(fminf(dot(va, axis), dot(vb, axis)), fminf(dot(vc, axis), dot(vd, axis)));
+        if (!(lo > 0.0f)) {
+            return v3(0.0f, 0.0f, 0.0f);
+        }
+    }
     float side = dot(n, axis);
     if (!(side > 0.0f)) {
         n = mulf(n, -1.0f);
@@ -538,8 +516,11 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     items.count = a.ns;
     if (CULL && a.cell_list != nullptr) {
         const uint32_t cell = (by >> a.cell_log2gy) * a.cells_x + (bx >> a.cell_log2gx);
-        items.list = a.cell_list + (size_t)cell * a.ns;
-        items.count = a.cell_count[cell];
+        const uint32_t listed = a.cell_count[cell];
+        if (listed <= a.cell_cap) { // else: the list did not fit; the whole scene is always a superset
+            items.list = a.cell_list + (size_t)cell * a.cell_cap;
+            items.count = listed;
+        }
     }
     if (ABL(1u)) items.count = 0u;
     const uint32_t ns = items.count;
@@ -842,41 +823,91 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     }
 }
 
-// Level 1 of the two-level culling used for large scenes.  Workgroup (cell, split) walks its share of
-// the sphere array and collects, for its coarse cell (a block of 2^gx x 2^gy macro tiles), the indices
-// of the spheres whose inflated bound can touch the cell's pyramid: same conservative test as the
-// per-tile one, on a larger rectangle.  Survivors are gathered in LDS and appended to the cell's list
-// with one atomic reservation per flush (cell_count must be zero at launch).  The order of the list
-// does not matter: the closest hit is the minimum of (t, creation index).
-constexpr int kBinCap = 2048; // indices gathered in LDS between flushes
+// Level 1 of the two-level culling used for large scenes: the scene is binned into coarse cells (blocks of
+// 2^gx x 2^gy macro tiles, a few hundred to a thousand of them) and every trace workgroup then stages its cell's
+// list instead of the whole scene.  ONE launch, two levels inside it: workgroup (block, split) walks its share of the
+// sphere array against the pyramid of a BLOCK of 4 x 4 cells -- the same conservative test as the per-tile one, on a
+// larger rectangle -- gathers the survivors in LDS (hoisted centre and culling margin, as the REFINE pass of the trace
+// kernel keeps them) and tests each of them against the 16 cell pyramids of the block, one (survivor, cell) pair
+// per thread.  Sound level by level: a sphere that a pixel ray of a cell can hit can be hit by a ray of the
+// cell's block.  Tests: blocks x spheres + 16 x survivors instead of cells x spheres.
+//
+// Lists are compact: cell c owns cell_cap entries (a few times the average; host: rtx_render_rows) and the
+// workgroups append with one reservation per cell and flush -- atomicAdd on the cell's counter, which keeps
+// counting past the capacity.  A trace workgroup that finds count > cell_cap stages the whole scene instead
+// (always a superset), so a list that does not fit costs time, never a pixel.  The order of a list does not
+// matter: the closest hit is the minimum of (t, creation index).
+//
+// The counters alternate between two buffers from launch to launch: this launch accumulates into
+// cell_count_out and zeroes the 16 counters of its block in cell_count_zero, which the next launch on this
+// stream accumulates into -- no memset between frames.
+constexpr int kBlockCells = 16; // cells per block: 4 x 4
+constexpr int kBinCap = 1024;   // block survivors gathered in LDS between cell phases
 
-// `owned`: this workgroup is the only one that writes the cell's list (one split), `written` entries so far: no
-// atomic and no zeroed counter needed; the caller stores the final count.
-__device__ __forceinline__ void bin_flush(uint32_t* s_out, uint32_t n, uint32_t* out, uint32_t* count, uint32_t* s_base, bool owned, uint32_t written)
+// Appends the block survivors [0, n) in s_rec / s_idx to the lists of the cells they can touch.
+__device__ __forceinline__ void bin_cells_of_block(const KArgs& a, const float4* s_rec, const uint32_t* s_idx, uint32_t n, const float4 (*s_cellfr)[5],
+                                                   uint32_t* s_cnt, uint32_t* s_base, uint32_t* s_pos, const uint32_t* s_cellid)
 {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        *s_base = owned ? written : atomicAdd(count, n);
+    const uint32_t tid = threadIdx.x;
+    __syncthreads(); // survivors complete
+    if (tid < (uint32_t)kBlockCells) {
+        s_cnt[tid] = 0u;
+        s_pos[tid] = 0u;
     }
     __syncthreads();
-    const uint32_t base = *s_base;
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) {
-        out[base + i] = s_out[i];
+    // pass 1: the pairs' verdicts (kept in a bit mask: pair p = tid + 256 i is bit i) and the cells' counts
+    const uint32_t pairs = n * (uint32_t)kBlockCells;
+    unsigned long long keep = 0ull;
+    for (uint32_t p = tid, i = 0; p < pairs; p += (uint32_t)kThreads, i++) {
+        const uint32_t sv = p >> 4, c = p & 15u;
+        if (s_cellid[c] == 0xffffffffu) {
+            continue; // cell beyond the edge of the grid
+        }
+        const float4 r = s_rec[sv];
+        bool out = false;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const float4 nk = s_cellfr[c][k];
+            out = out || (nk.x * r.x + nk.y * r.y + nk.z * r.z > r.w); // as tile_culls, margin in r.w (+inf: never)
+        }
+        if (!out) {
+            keep |= 1ull << i;
+            atomicAdd(&s_cnt[c], 1u);
+        }
     }
     __syncthreads();
+    if (tid < (uint32_t)kBlockCells && s_cnt[tid] != 0u) {
+        s_base[tid] = atomicAdd(a.cell_count_out + s_cellid[tid], s_cnt[tid]); // one reservation per cell and flush
+    }
+    __syncthreads();
+    for (uint32_t p = tid, i = 0; p < pairs; p += (uint32_t)kThreads, i++) {
+        if ((keep >> i) & 1ull) {
+            const uint32_t sv = p >> 4, c = p & 15u;
+            const uint32_t at = s_base[c] + atomicAdd(&s_pos[c], 1u);
+            if (at < a.cell_cap) {
+                a.cell_list_out[(size_t)s_cellid[c] * a.cell_cap + at] = s_idx[sv];
+            }
+        }
+    }
+    __syncthreads(); // the survivor buffer may be refilled
 }
 
 __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
 {
-    __shared__ uint32_t s_out[kBinCap];
+    static_assert(kBinCap * kBlockCells <= 64 * kThreads, "a thread's pairs must fit the 64-bit verdict mask");
+    __shared__ float4 s_rec[kBinCap];              // ox oy oz margin
+    __shared__ uint32_t s_idx[kBinCap];
+    __shared__ float4 s_cellfr[kBlockCells][5];
+    __shared__ uint32_t s_cellid[kBlockCells];     // global cell number, or 0xffffffff beyond the grid
+    __shared__ uint32_t s_cnt[kBlockCells], s_base[kBlockCells], s_pos[kBlockCells];
     __shared__ uint32_t s_wcnt[2][8];
     __shared__ float s_frustum[16];
-    __shared__ uint32_t s_base;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t tw = 1u << a.tile_log2w, th = (uint32_t)kThreads >> a.tile_log2w;
     const uint32_t nx = 1u << a.sub_log2nx, ny = a.nsub >> a.sub_log2nx;
     const uint32_t cw = (tw * nx) << a.cell_log2gx, ch = (th * ny) << a.cell_log2gy; // cell, pixels
-    const uint32_t cell = blockIdx.y * a.cells_x + blockIdx.x;
+    const uint32_t blocks_x = (a.cells_x + 3u) >> 2;
+    const uint32_t bby = blockIdx.x / blocks_x, bbx = blockIdx.x - bby * blocks_x;   // this workgroup's block of cells
 
     Camera cam;
 #pragma unroll
@@ -887,19 +918,31 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
     cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
     cam.fW = a.fW; cam.fH = a.fH;
 
-    TileFrustum fr;
-    if (tid < 64u) {
-        const TileFrustum f0 = tile_frustum(cam, blockIdx.x * cw, a.row0 + blockIdx.y * ch, cw, ch);
-        if (tid == 0u) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                s_frustum[3 * k + 0] = f0.n[k].x;
-                s_frustum[3 * k + 1] = f0.n[k].y;
-                s_frustum[3 * k + 2] = f0.n[k].z;
-            }
+    // pyramids: lanes 0..4 the block's five planes, lanes 5..84 plane k of cell c = (lane - 5) / 5
+    if (tid < 5u + 5u * (uint32_t)kBlockCells) {
+        if (tid < 5u) {
+            const V3 n = tile_plane(cam, bbx * 4u * cw, a.row0 + bby * 4u * ch, 4u * cw, 4u * ch, tid);
+            s_frustum[3 * tid + 0] = n.x;
+            s_frustum[3 * tid + 1] = n.y;
+            s_frustum[3 * tid + 2] = n.z;
+        } else {
+            const uint32_t q = tid - 5u, c = q / 5u, k = q - c * 5u;
+            const uint32_t cx = bbx * 4u + (c & 3u), cy = bby * 4u + (c >> 2);
+            const V3 n = tile_plane(cam, cx * cw, a.row0 + cy * ch, cw, ch, k);
+            s_cellfr[c][k] = make_float4(n.x, n.y, n.z, 0.0f);
+        }
+    }
+    if (tid < (uint32_t)kBlockCells) {
+        const uint32_t cx = bbx * 4u + (tid & 3u), cy = bby * 4u + (tid >> 2);
+        const bool valid = cx < a.cells_x && cy < a.cells_y;
+        s_cellid[tid] = valid ? cy * a.cells_x + cx : 0xffffffffu;
+        // the other counter buffer, for the next launch on this stream (one workgroup per block does it)
+        if (valid && blockIdx.y == 0u && a.cell_count_zero != nullptr) {
+            a.cell_count_zero[cy * a.cells_x + cx] = 0u;
         }
     }
     __syncthreads();
+    TileFrustum fr;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         fr.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
@@ -907,27 +950,17 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         fr.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
     }
 
-    uint32_t* out = a.cell_list_out + (size_t)cell * a.ns;
-    uint32_t* count = a.cell_count_out + cell;
-    // what this cell is binned from: the whole scene, or the list of its parent cell (a coarser launch's output)
     Items items;
     items.geom = a.sph_geom;
     items.list = nullptr;
     items.count = a.ns;
-    if (a.bin_in_list != nullptr) {
-        const uint32_t parent = (blockIdx.y >> a.bin_in_shift) * a.bin_in_px + (blockIdx.x >> a.bin_in_shift);
-        items.list = a.bin_in_list + (size_t)parent * a.ns;
-        items.count = a.bin_in_count[parent];
-    }
-    // this workgroup's share of the items: [lo, hi), a multiple of the step size except at the end
-    const uint32_t ns = items.count, splits = gridDim.z;
+    // this workgroup's share of the spheres: [lo, hi), a multiple of the step size except at the end
+    const uint32_t ns = a.ns, splits = gridDim.y;
     const uint32_t steps = (ns + kChunk - 1) / kChunk;
-    const uint32_t lo = (uint32_t)(((uint64_t)steps * blockIdx.z) / splits) * kChunk;
-    const uint32_t hi_raw = (uint32_t)(((uint64_t)steps * (blockIdx.z + 1)) / splits) * kChunk;
+    const uint32_t lo = (uint32_t)(((uint64_t)steps * blockIdx.y) / splits) * kChunk;
+    const uint32_t hi_raw = (uint32_t)(((uint64_t)steps * (blockIdx.y + 1)) / splits) * kChunk;
     const uint32_t hi = hi_raw < ns ? hi_raw : ns;
 
-    const bool owned = gridDim.z == 1u;
-    uint32_t written = 0;
     uint32_t total = 0, parity = 0;
     uint32_t k0, k1;
     float4 g0 = load_item(items, lo + tid, k0), g1 = load_item(items, lo + kThreads + tid, k1);
@@ -937,19 +970,22 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         g0 = load_item(items, base + kChunk + tid, k0);
         g1 = load_item(items, base + kChunk + kThreads + tid, k1);
         if (total > (uint32_t)(kBinCap - kChunk)) {
-            bin_flush(s_out, total, out, count, &s_base, owned, written);
-            written += total;
+            bin_cells_of_block(a, s_rec, s_idx, total, s_cellfr, s_cnt, s_base, s_pos, s_cellid);
             total = 0;
         }
         bool keep[2];
+        float4 rec[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t k = base + (uint32_t)h * kThreads + tid;
             const float ox = cam.ox - g[h].x, oy = cam.oy - g[h].y, oz = cam.oz - g[h].z;
             const float oo = ox * ox + oy * oy + oz * oz;
             const float cc = oo - (g[h].w * g[h].w);
-            float mg_unused;
-            keep[h] = (k < hi) && !(cc > 0.0f && tile_culls(fr, ox, oy, oz, oo, g[h].w, mg_unused));
+            float mg;
+            const bool culled = tile_culls(fr, ox, oy, oz, oo, g[h].w, mg);
+            keep[h] = (k < hi) && !(cc > 0.0f && culled);
+            // camera inside or on the sphere: never culled, by any pyramid
+            rec[h] = make_float4(ox, oy, oz, cc > 0.0f ? mg : __builtin_inff());
         }
         const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
         if (lane == 0) {
@@ -970,19 +1006,19 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         }
         const unsigned long long below = (1ull << lane) - 1ull;
         if (keep[0]) {
-            s_out[total + before + (uint32_t)__popcll(m0 & below)] = kk[0];
+            const uint32_t pos = total + before + (uint32_t)__popcll(m0 & below);
+            s_rec[pos] = rec[0];
+            s_idx[pos] = kk[0];
         }
         if (keep[1]) {
-            s_out[total + first_total + before1 + (uint32_t)__popcll(m1 & below)] = kk[1];
+            const uint32_t pos = total + first_total + before1 + (uint32_t)__popcll(m1 & below);
+            s_rec[pos] = rec[1];
+            s_idx[pos] = kk[1];
         }
         total = __builtin_amdgcn_readfirstlane(total + sum);
     }
     if (total) {
-        bin_flush(s_out, total, out, count, &s_base, owned, written);
-        written += total;
-    }
-    if (owned && tid == 0u) {
-        *count = written;
+        bin_cells_of_block(a, s_rec, s_idx, total, s_cellfr, s_cnt, s_base, s_pos, s_cellid);
     }
 }
 
@@ -1234,9 +1270,10 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     return name;
 }
 
-extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned cells_x, unsigned cells_y, unsigned splits, void* stream_v)
+extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned splits, void* stream_v)
 {
-    hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(cells_x, cells_y, splits), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
+    const unsigned blocks = ((a->cells_x + 3u) >> 2) * ((a->cells_y + 3u) >> 2);
+    hipLaunchKernelGGL(rtx::rtx_bin_cells, dim3(blocks, splits, 1), dim3(rtx::kThreads), 0, (hipStream_t)stream_v, *a);
     return (int)hipGetLastError();
 }
 

@@ -395,7 +395,7 @@ def test_many_planes_beyond_the_lds_table(R, ctx):
         assert_same(got, want, O.RGB_ASCII, 320, "40 planes %s" % kernel)
 
 
-@pytest.mark.parametrize("res", [(333, 77), (1025, 3), (7, 513), (2049, 5), (64, 64), (129, 257)])
+@pytest.mark.parametrize("res", [(333, 77), (1025, 3), (7, 513), (2049, 5), (64, 64), (129, 257), (5, 513), (9, 513), (7, 257), (16, 513)])
 def test_odd_frame_sizes_with_culling(R, ctx, res):
     """Frame sizes that are not multiples of any tile dimension, with enough spheres for the binned kernel
     and (forced) two-level culling; full frames and ragged row slabs."""
@@ -407,7 +407,7 @@ def test_odd_frame_sizes_with_culling(R, ctx, res):
     sc = O.Scene.from_arrays(sph, pl)
     want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=4)
     for two in (0, 1):
-        for sub in (0, 1, 3):
+        for sub in (0, 1, 3, 4):
             set_kernel(R, ctx, "binned", 0, sub, two)
             got = ctx.render_to_host(p, R.RGB_ASCII)
             assert_same(got, want, O.RGB_ASCII, w, "%dx%d two-level %d sub %d" % (w, h, two, sub))
@@ -555,3 +555,60 @@ def test_tile_order_with_a_moving_camera_changing_grids_and_slabs(R, ctx):
         ctx.synchronize()
         assert_same(buf.cpu().numpy()[:20 * w * h], want, R.RGB_ASCII, w, "tile order, slabs, step %d" % step)
     set_kernel(R, ctx, "auto", tile_order=16)
+
+
+# ---------------------------------------------------------------- compact coarse-cell lists (rtx_bin_cells)
+
+def test_cell_lists_that_do_not_fit_fall_back_to_the_whole_scene(R, ctx):
+    """RTX_OPT_CELL_CAPACITY far below what the cells need: every overflowing cell's workgroups stage the whole scene
+    instead of the (truncated) list -- slower, the same frame."""
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+    try:
+        for cap in (1, 7, 64, 0):
+            ctx.set_option(R.OPT_CELL_CAPACITY, cap)
+            for sub in (0, 2):
+                set_kernel(R, ctx, "binned", subtiles=sub, two_level=1)
+                assert O.fnv1a64(ctx.render_to_host(p, R.RGB_ASCII)) == gold, "capacity %d, sub-tiles %d" % (cap, sub)
+                assert O.fnv1a64(ctx.render_to_host(p, R.RGB_ASCII)) == gold, "capacity %d, second frame (counter buffers alternate)" % cap
+    finally:
+        ctx.set_option(R.OPT_CELL_CAPACITY, 0)
+        set_kernel(R, ctx, "auto")
+
+
+def test_a_million_spheres_and_scratch_proportional_to_the_scene(R):
+    """1 048 576 spheres on a small frame: the two-level kernel (compact lists: 4 ns / cells + 1024 entries per cell,
+    i.e. O(spheres) words of scratch, where round 1 used cells x ns) against the brute kernel, byte for byte; and
+    config 5's scratch stays below 8 MB."""
+    import torch
+    w, h = 320, 128
+    p = R.camera_params(w, h)
+    n = 1 << 20
+    sph, pl = R.synth_scene(11, n, 0, p.element1, p.element2)
+    with R.Context(1920, 1080) as c:
+        c.set_scene(sph, pl)
+        c.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        want = c.render_to_host(p, R.RGB_ASCII)
+        assert int((want.reshape(h, w, 20)[:, :w - 1, 2] == ord("3")).sum()) > 0.2 * w * h   # the scene does cover the frame
+        c.set_option(R.OPT_KERNEL, R.KERNEL_BINNED)
+        for two in (-1, 1):
+            c.set_option(R.OPT_TWO_LEVEL, two)
+            got = c.render_to_host(p, R.RGB_ASCII)
+            assert_same(got, want, R.RGB_ASCII, w, "1M spheres, two-level %d" % two)
+        # config 5 (65 536 spheres at 1080p): device memory taken by the first two-level frames
+        p5, sph5, pl5 = R.config_inputs("C5")
+        c.set_scene(sph5, pl5)
+        c.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        c.render_rows(p5, R.RGB_ASCII, 0, 8)          # uploads the scene
+        c.synchronize()
+        c.set_option(R.OPT_KERNEL, R.KERNEL_AUTO)
+        c.set_option(R.OPT_TWO_LEVEL, -1)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        got5 = c.render_to_host(p5, R.RGB_ASCII)
+        c.render(p5, R.RGB_ASCII)
+        c.synchronize()
+        free1 = torch.cuda.mem_get_info()[0]
+        assert O.fnv1a64(got5) == U.load_golden()["C5_RGB_ASCII"]["frame_fnv1a64"]
+        assert free0 - free1 <= 8 * 1024 * 1024, "two-level scratch for C5 took %.1f MB" % ((free0 - free1) / 1e6)

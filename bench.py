@@ -113,12 +113,15 @@ def main():
                     help="N=1: the K-step batch is repeated until this much GPU time has been measured; the median batch is reported")
     ap.add_argument("--max-repeats", type=int, default=2000)
     ap.add_argument("--root", default="rotate", choices=["rotate", "fixed"],
-                    help="N>1: frame i is assembled on rank i %% N (rotate) or always on rank 0 (fixed)")
+                    help="N>1: frame i is assembled on rank i %% N (rotate: highest throughput) or always on rank 0, in frame order "
+                         "(fixed: north_star's literal gather, in-order delivery to one consumer)")
     ap.add_argument("--exchange", default="compact", choices=["compact", "rounds", "p2p"],
                     help="N>1: compact (default) = frames in rounds of M*N with rotating roots, one RCCL all-to-all per "
                          "round, slabs as 4-byte pixel words expanded into records on the root; rounds = the same with "
                          "the slabs as records (M=1); p2p = one point-to-point gather per frame (see --root)")
-    ap.add_argument("--frames-per-root", type=int, default=0, help="N>1, --exchange compact: M (0 = 8/4/4 for 2/4/8 GPUs)")
+    ap.add_argument("--frames-per-root", type=int, default=0, help="N>1, --exchange compact: M (0 = 8/4/4 for 2/4/8 GPUs; 8 with --root fixed)")
+    ap.add_argument("--graphs", type=int, default=1, help="N>1, --exchange compact: record a round's slab launches (and its expansions) as HIP graphs (0 = off)")
+    ap.add_argument("--latency", action="store_true", help="N>1, --exchange compact: also stamp every frame's completion and report queue-to-complete latency")
     ap.add_argument("--frames-in-flight", type=int, default=4,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
                          "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
@@ -170,6 +173,8 @@ def main():
     if args.tile_order >= 0:
         ctx.set_option(R.OPT_TILE_ORDER, args.tile_order)
 
+    ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)
+    ctx.synchronize()
     K, Wm = args.steps, args.warmup
     bounds = sharding.row_bounds(H, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
@@ -312,9 +317,19 @@ def main():
             # rtx_submit_slabs), which the RCCL call is ordered after.  "compact": the slabs travel as 4-byte
             # pixel words and the root expands them into records on a side stream once the exchange is done.
             compact = args.exchange == "compact"
-            M = 1 if not compact else (args.frames_per_root or {2: 8, 4: 4, 8: 4}.get(world, max(1, 16 // world)))
+            fixed_root = args.root == "fixed"      # in-order delivery: every frame assembled on rank 0, in frame order
+            roots = [0] if fixed_root else None
+            M = 1 if not compact else (args.frames_per_root or ({2: 8, 4: 8, 8: 8} if fixed_root else {2: 8, 4: 4, 8: 4}).get(world, max(1, 16 // world)))
             post = torch.cuda.Stream()
             expanders = {}
+            use_graphs = [compact and args.graphs != 0]
+            slab_graphs, expand_graphs = {}, {}
+            # per-frame latency: an event when a round's slab launches are queued, one when each of its frames is
+            # complete on its root (pools of timing events, reused round-robin; read after the timed region)
+            POOL = 64
+            ev_submit = [torch.cuda.Event(enable_timing=True) for _ in range(POOL)]
+            ev_done = [[torch.cuda.Event(enable_timing=True) for _ in range(max(1, M))] for _ in range(POOL)]
+            done_count = {}
 
             class _After:
                 def __init__(self, ev):
@@ -323,42 +338,97 @@ def main():
                 def wait(self):
                     torch.cuda.current_stream().wait_event(self.ev)
 
+            def graph_or_none(build, on_stream, what):
+                """Records what build() queues on `on_stream` as a HIP graph; None (and no more attempts) if that fails."""
+                if not use_graphs[0]:
+                    return None
+                try:
+                    ctx.graph_begin(on_stream)
+                    try:
+                        build()
+                    finally:
+                        g = ctx.graph_end(on_stream)
+                    return ctx.graph_launcher(g, on_stream)
+                except R.RtxError as exc:
+                    sys.stderr.write("bench.py: HIP graph capture of the %s failed (%s); queueing launch by launch\n" % (what, exc))
+                    use_graphs[0] = False
+                    return None
+
             def finish(q, b, work, mine):
                 with torch.cuda.stream(post):
                     work.wait()   # orders `post` (only) after the exchange
+                    key = (b, len(mine))
                     for m, segs in mine:
-                        key = (b, m, len(mine))
-                        if key not in expanders:
-                            expanders[key] = ctx.make_expander(mode, pipe.recv[b].data_ptr(), pipe.frames[b][m].data_ptr(), segs, post.cuda_stream)
-                        expanders[key]()
+                        ek = (b, m, len(mine))
+                        if ek not in expanders:
+                            expanders[ek] = ctx.make_expander(mode, pipe.recv[b].data_ptr(), pipe.frames[b][m].data_ptr(), segs, post.cuda_stream)
+                    if args.latency:
+                        # frame by frame, so that every frame's completion can be stamped (frames leave in frame order)
+                        for m, _ in mine:
+                            expanders[(b, m, len(mine))]()
+                            ev_done[q % POOL][m].record(post)
+                        done_count[q % POOL] = (q, len(mine))
+                    else:
+                        if mine and key not in expand_graphs:
+                            expand_graphs[key] = graph_or_none(lambda: [expanders[(b, m, len(mine))]() for m, _ in mine], post.cuda_stream, "expansions")
+                        if mine and expand_graphs.get(key) is not None:
+                            expand_graphs[key]()
+                        else:
+                            for m, _ in mine:
+                                expanders[(b, m, len(mine))]()
                     ev = torch.cuda.Event()
                     ev.record(post)
                 return _After(ev)
 
             pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, frames_per_root=M,
-                                             pixel_bytes=4 if compact else None, finish=finish if compact else None)
+                                             pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
             F = max(1, args.frames_in_flight)
             rstreams = [torch.cuda.Stream() for _ in range(F)]
             torch.cuda.synchronize()
             RF = pipe.round_frames
             submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,
-                                                  [pipe.unit(b, f).data_ptr() if rows else pipe.frames[b][0].data_ptr() for f in range(RF)],
+                                                  [pipe.unit(b, f).data_ptr() if rows else pipe.send[b].data_ptr() for f in range(RF)],
                                                   [rstreams[f % F].cuda_stream for f in range(RF)], stream.cuda_stream,
                                                   flags=R.RENDER_COMPACT if compact else 0)
                           for b in range(pipe.nbuf)]
 
             def render_round(q, b, nframes):
-                if rows:
-                    submitters[b](nframes)
+                if args.latency:
+                    ev_submit[q % POOL].record(stream)
+                if not rows:
+                    return
+                if nframes == RF and use_graphs[0]:
+                    # a full round's slab launches (forked over the render streams, joined back) as one graph replay
+                    if b not in slab_graphs:
+                        slab_graphs[b] = graph_or_none(lambda: submitters[b](RF), stream.cuda_stream, "slab launches")
+                    if slab_graphs.get(b) is not None:
+                        slab_graphs[b]()
+                        return
+                submitters[b](nframes)
 
             elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize,
                                                 prewarm=int(args.prewarm_ms * 40))   # ~25 us per frame on one GPU
             n_rounds = -(-K // RF)
             last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
             slab0 = pipe.unit(0, 0)
-            exchange_note = ("frames in rounds of %d (M=%d per root), frame i of a round assembled on rank i %% N by one RCCL all-to-all per round; "
-                             % (RF, M)) + ("slabs travel as 4-byte pixel words, the root expands them into records (rtx_expand)" if compact
-                                           else "slabs travel as records")
+            latency = None
+            if args.latency and compact:
+                # queued -> complete on the root, for the frames of the last rounds still in the event pools
+                lat = []
+                for slot, (q, n) in done_count.items():
+                    if q0 <= q < q0 + n_rounds:
+                        for m in range(n):
+                            lat.append(ev_submit[slot].elapsed_time(ev_done[slot][m]))
+                t = torch.tensor([median(lat) if lat else -1.0, max(lat) if lat else -1.0], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                latency = {"median_ms": round(float(t[0].item()), 4), "max_ms": round(float(t[1].item()), 4),
+                           "of": "a frame, from the queueing of its round's slab launches to the complete frame on its root (HIP events; "
+                                 "worst rank); a round is %d frames" % RF}
+            exchange_note = ("frames in rounds of %d (M=%d per root), %s by one RCCL all-to-all per round; "
+                             % (RF, M, "every frame assembled on rank 0 in frame order (in-order delivery)" if fixed_root
+                                else "frame i of a round assembled on rank i %% N")) + \
+                            ("slabs travel as 4-byte pixel words, the root expands them into records (rtx_expand)" if compact
+                             else "slabs travel as records") + ("; HIP graph per round" if use_graphs[0] and slab_graphs else "")
         else:
             pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
 
@@ -374,6 +444,8 @@ def main():
             exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
         final = None
         timing = {"method": "wall clock around exactly K frames, barrier + synchronize on both sides, MAX over ranks", "repeats": 1}
+        if args.exchange in ("compact", "rounds") and latency is not None:
+            timing["frame_latency"] = latency
         dist_verified = None
         if not args.no_verify:
             # byte check of the last assembled frame, outside the timed region: its root hashes it (SHA-256 of the

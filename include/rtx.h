@@ -192,6 +192,20 @@ int rtx_submit_slabs(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode,
 int rtx_expand(rtx_ctx* ctx, int mode, const void* d_compact, void* d_out, const rtx_segment* segments,
                size_t n_segments, void* stream);
 
+/* ---- replayable launch sequences (HIP graphs): a frame loop that queues the same launches round after round (the
+ * row-sharded loop: a round's slab launches, a round's expansions) pays one host call per replay instead of one per
+ * launch.  rtx_graph_begin puts `stream` (a hipStream_t) into capture; the rtx_submit_slabs / rtx_submit_frames /
+ * rtx_render_rows / rtx_expand calls that follow on it (rtx_submit_slabs may fork to its other streams and joins them
+ * back) are recorded instead of executed; rtx_graph_end ends the capture and returns an executable graph;
+ * rtx_graph_launch replays it on a stream.  Recorded launches keep their arguments (camera, buffers, row range).
+ * Not recordable, and reported as RTX_ERR_INVALID_ARGUMENT: a launch that needs a scene upload (render once before
+ * capturing), the two-level pre-pass or the tile-order refresh (both alternate buffers from launch to launch).
+ * No reference counterpart (one launch per frame on the default stream, RayTracingManager.cu:127-134). */
+int rtx_graph_begin(rtx_ctx* ctx, void* stream);
+int rtx_graph_end(rtx_ctx* ctx, void* stream, void** graph_out);
+int rtx_graph_launch(rtx_ctx* ctx, void* graph, void* stream);
+void rtx_graph_destroy(rtx_ctx* ctx, void* graph);
+
 int rtx_synchronize(rtx_ctx* ctx);
 
 /* The context's device result buffer (m_deviceResultArray, RayTracingManager.h:45) and its size. */

@@ -70,6 +70,10 @@ _SIGNATURES = [
     ("rtx_submit_slabs", C.c_int, [_P, C.c_size_t, C.POINTER(Params), C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_P), C.c_size_t,
                                    C.POINTER(_P), _P, C.c_uint]),
     ("rtx_expand", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_size_t, _P]),
+    ("rtx_graph_begin", C.c_int, [_P, _P]),
+    ("rtx_graph_end", C.c_int, [_P, _P, C.POINTER(_P)]),
+    ("rtx_graph_launch", C.c_int, [_P, _P, _P]),
+    ("rtx_graph_destroy", None, [_P, _P]),
     ("rtx_synchronize", C.c_int, [_P]),
     ("rtx_frame_device_ptr", _P, [_P]),
     ("rtx_frame_capacity", C.c_size_t, [_P]),
@@ -343,6 +347,29 @@ class Context:
                 self._check(rc)
         expand._keep = sa
         return expand
+
+    # -- HIP graphs: record a launch sequence once, replay it with one host call
+    def graph_begin(self, stream=None):
+        self._check(lib().rtx_graph_begin(self._h, stream))
+
+    def graph_end(self, stream=None):
+        g = _P()
+        self._check(lib().rtx_graph_end(self._h, stream, C.byref(g)))
+        return g
+
+    def graph_launcher(self, graph, stream=None):
+        """A callable that replays `graph` on `stream` (pre-bound: one foreign call per replay)."""
+        fn, h = lib().rtx_graph_launch, self._h
+
+        def launch():
+            rc = fn(h, graph, stream)
+            if rc != OK:
+                self._check(rc)
+        launch._keep = graph
+        return launch
+
+    def graph_destroy(self, graph):
+        lib().rtx_graph_destroy(self._h, graph)
 
     def synchronize(self):
         self._check(lib().rtx_synchronize(self._h))

@@ -149,10 +149,13 @@ def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize, 
 
 
 class RowShardedRounds:
-    """The N > 1 frame loop with one exchange per round of M*N frames.
+    """The N > 1 frame loop with one exchange per round of M*R frames, R = the number of root ranks.
 
-    Frame f of a round (f = m*N + j, m < M) is assembled on rank j: consecutive frames rotate over the roots
-    and every root receives M frames per round.  In a round every rank renders its row slab of each of the
+    `roots` (ascending rank numbers; default: every rank) are the ranks frames are assembled on.  Frame f of a
+    round (f = m*R + i, m < M) is assembled on roots[i]: consecutive frames rotate over the roots and every root
+    receives M frames per round.  roots = [0] is the in-order form: every frame is assembled on rank 0, in frame
+    order (what the reference's single consumer, PrintMachine::SetDataInBackBuffer, RayTracingManager.cu:150,
+    expects), as one gather per M frames.  In a round every rank renders its row slab of each of the
     round's frames into one send buffer (the slab of frame f at unit (j*M + m), so that everything bound for
     rank j is contiguous) and ONE all_to_all_single moves it: per round each directed xGMI link carries M
     slabs, and the per-call cost of the collective (of the order of a whole frame's trace) is paid once per
@@ -177,8 +180,13 @@ class RowShardedRounds:
     Buffers are rings of `nbuf`, so the exchange of a round overlaps the rendering of the next."""
 
     def __init__(self, dist, torch, rank, world, width, height, record_size, device, nbuf=2, frames_per_root=1, pixel_bytes=None,
-                 finish=None):
+                 finish=None, roots=None):
         self.dist, self.torch, self.rank, self.world = dist, torch, rank, world
+        self.roots = list(range(world)) if roots is None else sorted(set(int(r) for r in roots))
+        if not self.roots or self.roots[0] < 0 or self.roots[-1] >= world:
+            raise ValueError("roots must be rank numbers")
+        self.R = len(self.roots)
+        self.root_index = {r: i for i, r in enumerate(self.roots)}
         self.W, self.H, self.S, self.nbuf, self.M = width, height, record_size, nbuf, frames_per_root
         self.px = record_size if pixel_bytes is None else pixel_bytes
         self.expanding = self.px != record_size
@@ -191,12 +199,14 @@ class RowShardedRounds:
         self.row0 = self.bounds[rank]
         self.rows = self.bounds[rank + 1] - self.bounds[rank]
         self.unit_len = self.px * width * self.rows
-        self.round_frames = self.M * world
+        self.round_frames = self.M * self.R
         self.send = [torch.zeros(self.round_frames * self.unit_len, dtype=torch.uint8, device=device) for _ in range(nbuf)]
-        # 20*W*H bytes each: the reference's frame size whatever the mode (PrintMachine.cpp:140)
-        self.frames = [[torch.zeros(20 * width * height, dtype=torch.uint8, device=device) for _ in range(self.M)] for _ in range(nbuf)]
+        # 20*W*H bytes each: the reference's frame size whatever the mode (PrintMachine.cpp:140); only roots hold frames
+        self.is_root = rank in self.root_index
+        self.frames = [[torch.zeros(20 * width * height if self.is_root else 0, dtype=torch.uint8, device=device) for _ in range(self.M)]
+                       for _ in range(nbuf)]
         self.recv = None
-        if self.expanding:
+        if self.expanding and self.is_root:
             self.recv = [torch.zeros(self.M * self.px * width * height, dtype=torch.uint8, device=device) for _ in range(nbuf)]
         self.nothing = torch.zeros(0, dtype=torch.uint8, device=device)
         self.pending = [None] * nbuf
@@ -205,16 +215,19 @@ class RowShardedRounds:
         self._full_splits = None
 
     def root_of(self, i):
-        return i % self.world
+        return self.roots[i % self.R]
 
     def unit(self, b, f):
         """The send-buffer slot of frame f of a round (this rank's rows of it)."""
-        k = (f % self.world) * self.M + f // self.world
+        k = (f % self.R) * self.M + f // self.R
         return self.send[b][k * self.unit_len:(k + 1) * self.unit_len]
 
     def frames_for_root(self, j, nframes):
         """How many of a round's first `nframes` frames are rooted on rank j."""
-        return 0 if nframes <= j else (nframes - j + self.world - 1) // self.world
+        i = self.root_index.get(j)
+        if i is None or nframes <= i:
+            return 0
+        return (nframes - i + self.R - 1) // self.R
 
     def segments(self, m, mine):
         """Frame m of this root in recv[b] when `mine` frames arrived: (src pixel, dst pixel, pixels) per rank."""
@@ -257,8 +270,9 @@ class RowShardedRounds:
             inp = self._present_units(b, nframes)
         work = self.dist.all_to_all_single(out, inp, outs, ins, async_op=True)
         for m in range(mine):
-            self.where[q * self.round_frames + m * N + self.rank] = (b, m)
-            self.where.pop((q - self.nbuf) * self.round_frames + m * N + self.rank, None)   # overwritten by now
+            i = self.root_index[self.rank]
+            self.where[q * self.round_frames + m * self.R + i] = (b, m)
+            self.where.pop((q - self.nbuf) * self.round_frames + m * self.R + i, None)   # overwritten by now
         if self.finish is not None:
             if mine not in self._mine_cache:   # the segment lists depend on `mine` only: built once
                 self._mine_cache[mine] = [(m, self.segments(m, mine)) for m in range(mine)] if self.expanding else []
@@ -270,10 +284,10 @@ class RowShardedRounds:
         """Partial round: the present units of each destination, packed (all_to_all_single wants one contiguous
         input).  Only the last round of a run takes this path."""
         parts = []
-        for j in range(self.world):
+        for i, j in enumerate(self.roots):
             k = self.frames_for_root(j, nframes)
             if k:
-                parts.append(self.send[b][j * self.M * self.unit_len:(j * self.M + k) * self.unit_len])
+                parts.append(self.send[b][i * self.M * self.unit_len:(i * self.M + k) * self.unit_len])
         if not parts:
             return self.nothing
         return self.torch.cat(parts)

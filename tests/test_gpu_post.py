@@ -346,3 +346,66 @@ def test_compact_rejects_what_it_cannot_do(R, ctx):
         ctx.expand(R.SDL, buf.data_ptr(), buf.data_ptr(), [(0, 0, 16)])
     with pytest.raises(R.RtxError):
         ctx.expand(R.RGB_ASCII, buf.data_ptr() + 2, buf.data_ptr(), [(0, 0, 16)])            # misaligned
+
+
+def test_hip_graph_replays_a_round_of_slabs_and_their_expansion(R, ctx):
+    """rtx_graph_begin / _end / _launch: a round of the row-sharded loop -- the slab launches of several frames forked over
+    render streams and joined back, then the expansion of the compact words into records -- recorded once and replayed
+    with one host call each; every replay must leave exactly the bytes the direct calls leave.  What cannot be recorded
+    (the two-level pre-pass) is refused and the stream leaves capture mode."""
+    import torch
+    p0, sph, pl = R.config_inputs("C2")
+    ctx.set_option(R.OPT_KERNEL, R.KERNEL_AUTO)
+    ctx.set_option(R.OPT_TWO_LEVEL, -1)
+    ctx.set_scene(sph, pl)
+    W, H = int(p0.x), int(p0.y)
+    row0, rows, n = 405, 270, 5
+    params = [R.camera_params(W, H, pos=(0.1 * i, 0.0, 0.0), rot=(0.0, np.pi + 0.02 * i, 0.0)) for i in range(n)]
+    main = torch.cuda.Stream()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    words = torch.zeros(n, W * rows, dtype=torch.int32, device="cuda")
+    recs = torch.zeros(n, 20 * W * rows, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    segs = [(0, 0, W * rows)]
+
+    def queue_round():
+        ctx.submit_slabs(params, R.RGB_ASCII, row0, rows, [words[i].data_ptr() for i in range(n)], row0,
+                         [streams[i % 3].cuda_stream for i in range(n)], after=main.cuda_stream, flags=R.RENDER_COMPACT)
+        for i in range(n):
+            ctx.expand(R.RGB_ASCII, words[i].data_ptr(), recs[i].data_ptr(), segs, stream=main.cuda_stream)
+
+    queue_round()                         # also uploads the scene: a capture must not have to
+    torch.cuda.synchronize()
+    want = recs.cpu().numpy().copy()
+    for i in range(n):                    # the records are what the oracle renders for that frame's camera
+        if i in (0, n - 1):
+            o = O.render(U.oracle_params(params[i]), O.Scene.from_arrays(sph, pl), O.RGB_ASCII, threads=8, )
+            assert np.array_equal(want[i], o[20 * W * row0:20 * W * (row0 + rows)])
+    ctx.graph_begin(main.cuda_stream)
+    queue_round()
+    g = ctx.graph_end(main.cuda_stream)
+    replay = ctx.graph_launcher(g, main.cuda_stream)
+    for _ in range(3):
+        words.zero_()
+        recs.fill_(0xEE)
+        torch.cuda.synchronize()
+        replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(recs.cpu().numpy(), want)
+    ctx.graph_destroy(g)
+    # not recordable: the two-level pre-pass; the error is reported and the stream is usable afterwards
+    ctx.set_option(R.OPT_TWO_LEVEL, 1)
+    ctx.graph_begin(main.cuda_stream)
+    with pytest.raises(R.RtxError) as e:
+        ctx.render_rows(params[0], R.RGB_ASCII, row0, rows, d_out=recs[0].data_ptr(), out_row_base=row0, stream=main.cuda_stream)
+    assert e.value.status == R.ERR_INVALID_ARGUMENT
+    try:
+        ctx.graph_destroy(ctx.graph_end(main.cuda_stream))
+    except R.RtxError:
+        pass                              # an empty or invalidated capture may be reported; either way it has ended
+    ctx.set_option(R.OPT_TWO_LEVEL, -1)
+    recs.fill_(0xEE)
+    torch.cuda.synchronize()
+    queue_round()
+    torch.cuda.synchronize()
+    assert np.array_equal(recs.cpu().numpy(), want)

@@ -130,7 +130,7 @@ def _frame_params(R, W, H, i):
     return R.camera_params(W, H, pos=(0.05 * i, 0.0, 0.0), rot=(0.0, np.pi + 0.01 * i, 0.0))
 
 
-def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path):
+def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path, roots=None):
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (here, os.path.dirname(here)):
         if p not in sys.path:
@@ -157,7 +157,8 @@ def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path):
             return None
 
         pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cpu", nbuf=2, frames_per_root=M,
-                                         pixel_bytes=4 if compact else None, finish=finish if compact else None)
+                                         pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
+        rts = list(range(world)) if roots is None else roots
 
         def render_round(q, b, nframes):
             # the oracle stands in for rtx_submit_slabs: this rank's rows of the round's first nframes frames
@@ -181,8 +182,8 @@ def _rounds_worker(rank, world, port, steps, warmup, M, compact, out_path):
         n_last = steps - (rounds - 1) * pipe.round_frames
         for f in range(n_last):
             i = last_q * pipe.round_frames + f
-            assert pipe.root_of(i) == f % world
-            if f % world == rank:
+            assert pipe.root_of(i) == rts[f % len(rts)]
+            if rts[f % len(rts)] == rank:
                 want = O.render(U.oracle_params(_frame_params(R, W, H, i)), sc, mode)
                 ok &= int(np.array_equal(pipe.frame(i).numpy(), want))
         t = torch.tensor([ok], dtype=torch.int64)
@@ -203,6 +204,37 @@ def test_bench_round_pipeline_over_gloo(tmp_path, world, steps, warmup, M, compa
     out = str(tmp_path / "ok.npy")
     mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, M, compact, out), nprocs=world, join=True)
     assert int(np.load(out)[0]) == 1
+
+
+@pytest.mark.parametrize("world,steps,warmup,M,compact", [(2, 7, 2, 3, True), (3, 8, 1, 2, True), (2, 4, 1, 1, False), (3, 5, 0, 1, False)])
+def test_in_order_delivery_on_rank0_over_gloo(tmp_path, world, steps, warmup, M, compact):
+    """roots = [0]: north_star's literal form -- every frame gathered on rank 0, in frame order, M frames per
+    collective (compact words expanded there, or records landing as the finished frame)."""
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_rounds_worker, args=(world, _free_port(), steps, warmup, M, compact, out, [0]), nprocs=world, join=True)
+    assert int(np.load(out)[0]) == 1
+
+
+def test_round_bookkeeping_with_a_subset_of_roots():
+    import importlib
+    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
+    for world, roots, M in ((4, [0], 3), (4, [1, 3], 2), (8, [0], 8), (3, [0, 1, 2], 2)):
+        for rank in range(world):
+            pipe = sharding.RowShardedRounds(None, torch, rank, world, 6, 11, 20, "cpu", nbuf=1, frames_per_root=M, pixel_bytes=4,
+                                             finish=lambda *a: None, roots=roots)
+            RF = pipe.round_frames
+            assert RF == M * len(roots)
+            for nframes in range(RF + 1):
+                for j in range(world):
+                    want = sum(1 for f in range(nframes) if roots[f % len(roots)] == j)
+                    assert pipe.frames_for_root(j, nframes) == want
+            for f in range(RF):
+                assert pipe.root_of(f) == roots[f % len(roots)] == pipe.root_of(f + 5 * RF)
+            # the units bound for one root are adjacent, roots in ascending order
+            for i, j in enumerate(roots):
+                ks = [((f % len(roots)) * M + f // len(roots)) for f in range(RF) if roots[f % len(roots)] == j]
+                assert ks == list(range(i * M, (i + 1) * M))
+            assert (pipe.frames[0][0].numel() > 0) == (rank in roots)
 
 
 def test_round_bookkeeping_without_a_process_group():

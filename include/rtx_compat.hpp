@@ -7,10 +7,11 @@
 //   MyMath::Vector3 / Vector4 / Matrix      MyMath.h:5-321   (PODs here: no vptrs travel to the GPU)
 //   DeviceObjectArray<T>, Object3D          Object3D.h:6-12, 36-65 (opaque handle here)
 //   RayTracingCPUToGPUData, RenderingMode   RayTracingManager.h:9-21
-//   PrintMachine (headless)                 PrintMachine.h:16-45: Start, GetMaxSize, GetWidth, GetHeight,
-//                                           SetDataInBackBuffer, GetBackBuffer, GetPrintSize
+//   PrintMachine                            PrintMachine.h:16-45: Start, GetMaxSize, GetWidth, GetHeight,
+//                                           SetDataInBackBuffer, GetBackBuffer, GetPrintSize; the printer thread
+//                                           (PrintMachine.cpp:257-306) for a POSIX terminal via StartPrinter(fd)
 //   Scene3D                                 Scene3D.h:15-25
-//   Camera3D                                Camera3D.h:12-31 (Init, Update, SetRot, SetPos, getters)
+//   Camera3D                                Camera3D.h:12-48 (Init, Update, Move, AddRot, m_Keys, SetRot, SetPos, getters)
 //   RayTracingManager                       RayTracingManager.h:27-37
 //   RayTracing::RayTrace                    RayTracing.h:31-38
 //
@@ -23,13 +24,21 @@
 
 #include "rtx.h"
 
+#include <cerrno>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
 #include <cstddef>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <unistd.h>
 
 namespace MyMath {
 
@@ -163,8 +172,14 @@ struct Device {
 } // namespace rtx_compat
 
 // ---------------------------------------------------------------------------------------------
-// Headless PrintMachine: the statics the hot path calls (RayTracingManager.cu:58,150,306), with the
-// double buffer and mutex of PrintMachine.cpp:178-192 but no console and no printer thread.
+// PrintMachine: the statics the hot path calls (RayTracingManager.cu:58,150,306) with the double buffer and mutex of
+// PrintMachine.cpp:178-192, and -- on request -- the printer thread of PrintMachine.cpp:257-306 for a POSIX
+// terminal: StartPrinter(fd) spawns it; it swaps the back buffer in under the mutex, homes the cursor with an ANSI
+// escape (the reference calls SetConsoleCursorPosition(0,0)) and writes the frame to fd.  Without StartPrinter the
+// class is headless (the caller reads GetBackBuffer / GetPrintSize itself).  One deliberate difference: the
+// reference's thread re-prints the same buffer in a busy loop between frames; this one sleeps on a condition
+// variable until SetDataInBackBuffer flags a new frame (a terminal gains nothing from identical bytes), and a frame
+// that arrives while the previous one is still being written replaces it, as in the reference.
 class PrintMachine {
 public:
     static void Start(const size_t x, const size_t y)
@@ -174,10 +189,15 @@ public:
         s.height = y;
         s.maxSize = 20 * x * y; // m_charsPerPixel, PrintMachine.h:81
         s.backBuffer.assign(s.maxSize, 0);
+        s.printBuffer.assign(s.maxSize, 0);
         s.backBufferPrintSize = 0;
         s.shouldSwap = false;
     }
-    static void CleanUp() { rtx_compat::Device::release(); }
+    static void CleanUp()
+    {
+        StopPrinter();
+        rtx_compat::Device::release();
+    }
     static size_t GetWidth() { return state().width; }
     static size_t GetHeight() { return state().height; }
     static size_t GetMaxSize() { return state().maxSize; }
@@ -190,21 +210,114 @@ public:
     static void SetDataInBackBuffer(const char* data, const size_t size)
     {
         State& s = state();
-        std::lock_guard<std::mutex> lock(s.mutex);
-        std::memcpy(s.backBuffer.data(), data, size);
-        s.shouldSwap = true;
-        s.backBufferPrintSize = size;
+        {
+            std::lock_guard<std::mutex> lock(s.mutex);
+            std::memcpy(s.backBuffer.data(), data, size);
+            s.shouldSwap = true; // FlagForBufferSwap
+            s.backBufferPrintSize = size;
+            s.framesSet++;
+        }
+        s.wake.notify_all();
     }
     static const char* GetBackBuffer() { return state().backBuffer.data(); }
     static size_t GetPrintSize() { return state().backBufferPrintSize; }
-    static void UpdateRenderingFPS(const int) {}
+    static void UpdateRenderingFPS(const int fps) { state().renderingFps = fps; }
+
+    // ---- the printer thread (PrintMachine::Start spawns and detaches it, PrintMachine.cpp:150-151; here it is joined
+    // by StopPrinter / CleanUp).  status_lines: print the two FPS lines after every frame as the reference does.
+    static void StartPrinter(int fd, bool status_lines = true)
+    {
+        State& s = state();
+        if (s.printer.joinable()) return;
+        s.fd = fd;
+        s.statusLines = status_lines;
+        s.terminate = false;
+        s.printer = std::thread(&PrintMachine::Print);
+    }
+    static void StopPrinter()
+    {
+        State& s = state();
+        if (!s.printer.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lock(s.mutex);
+            s.terminate = true; // m_terminateThread
+        }
+        s.wake.notify_all();
+        s.printer.join();
+    }
+    // Blocks until every frame handed to SetDataInBackBuffer so far has been written (a lock-step caller: tests).
+    static void WaitPrinted()
+    {
+        State& s = state();
+        std::unique_lock<std::mutex> lock(s.mutex);
+        s.done.wait(lock, [&] { return s.framesPrinted == s.framesSet || !s.printer.joinable() || s.terminate; });
+    }
+    static unsigned long long FramesPrinted() { return state().framesPrinted; }
 
 private:
+    static void write_all(int fd, const char* p, size_t n)
+    {
+        while (n > 0) {
+            const ssize_t w = ::write(fd, p, n);
+            if (w < 0) {
+                if (errno == EINTR || errno == EAGAIN) continue;
+                return; // the terminal went away
+            }
+            p += w;
+            n -= (size_t)w;
+        }
+    }
+    static bool Print() // PrintMachine.cpp:257-306
+    {
+        State& s = state();
+        auto second = std::chrono::steady_clock::now();
+        int printed_this_second = 0, printing_fps = 0;
+        for (;;) {
+            size_t size = 0;
+            unsigned long long upto = 0;
+            {
+                std::unique_lock<std::mutex> lock(s.mutex);
+                s.wake.wait(lock, [&] { return s.shouldSwap || s.terminate; });
+                if (s.terminate && !s.shouldSwap) break;
+                s.shouldSwap = false;
+                size = s.backBufferPrintSize;     // m_printSize = m_backBufferPrintSize
+                s.printBuffer.swap(s.backBuffer); // m_printBuffer.swap(m_backBuffer)
+                upto = s.framesSet;
+            }
+            write_all(s.fd, "\x1b[H", 3);         // ResetConsolePointer: cursor home
+            write_all(s.fd, s.printBuffer.data(), size);
+            printed_this_second++;
+            const auto now = std::chrono::steady_clock::now();
+            if (now - second >= std::chrono::seconds(1)) {
+                printing_fps = printed_this_second;
+                printed_this_second = 0;
+                second = now;
+            }
+            if (s.statusLines) {
+                char line[128];
+                const int n = std::snprintf(line, sizeof line, "\x1b[mRendering FPS: %d    \nPrinting FPS: %d    \n", s.renderingFps, printing_fps);
+                write_all(s.fd, line, (size_t)n);
+            } else {
+                write_all(s.fd, "\x1b[m", 3);
+            }
+            {
+                std::lock_guard<std::mutex> lock(s.mutex);
+                s.framesPrinted = upto;
+            }
+            s.done.notify_all();
+        }
+        s.done.notify_all();
+        return true;
+    }
     struct State {
         size_t width = 0, height = 0, maxSize = 0, backBufferPrintSize = 0;
-        std::vector<char> backBuffer;
-        std::mutex mutex;
-        bool shouldSwap = false;
+        std::vector<char> backBuffer, printBuffer;
+        std::mutex mutex; // m_backBufferMutex
+        std::condition_variable wake, done;
+        bool shouldSwap = false, terminate = false, statusLines = true;
+        unsigned long long framesSet = 0, framesPrinted = 0;
+        int fd = 1, renderingFps = 0;
+        std::thread printer;
     };
     static State& state()
     {
@@ -263,8 +376,40 @@ private:
 // rtx_camera_params so that there is one implementation of it.
 class Camera3D {
 public:
+    struct PressedKeys { // Camera3D.h:37-46
+        int W = 0, A = 0, S = 0, D = 0, Shift = 0, Space = 0;
+    };
+    PressedKeys m_Keys;
+
     void Init() { refresh(); }
     void Update() { refresh(); }
+    // Camera3D::Move, Camera3D.cpp:142-163: WASD in the x-z plane along the "static" right / forward vectors of the last
+    // Update (:61-71; their y components take no part), Space / Shift along y; speed 10 units per second; the summed
+    // direction is normalised with the safe host normalise (MyMath.h:117-123), so diagonals are not faster.
+    void Move(const long double dt)
+    {
+        const float deltaSpeed = static_cast<float>(dt) * 10.0f;
+        const MyMath::Vector3 moveX = m_staticRight * static_cast<float>(m_Keys.D - m_Keys.A);
+        const MyMath::Vector3 moveZ = m_staticForward * static_cast<float>(m_Keys.W - m_Keys.S);
+        MyMath::Vector3 total = moveX + moveZ;
+        const float length = std::sqrt(total.x * total.x + total.y * total.y + total.z * total.z);
+        const float divider = length < 0.000001f ? 0.0f : 1.0f / length;
+        total = total * divider;
+        m_pos.x = m_pos.x + (total.x * deltaSpeed);
+        m_pos.z = m_pos.z + (total.z * deltaSpeed);
+        m_pos.y += (float)(m_Keys.Space - m_Keys.Shift) * deltaSpeed;
+    }
+    // Camera3D::AddRot, Camera3D.cpp:166-187: p / y / r are mouse counts; 0.002 rad per count whatever dt; pitch clamped
+    // just inside +-pi/2.
+    void AddRot(const long double, const short p, const short y, const short r)
+    {
+        const float deltaSpeed = 0.002f;
+        m_rot.x -= ((float)p * deltaSpeed);
+        m_rot.y += ((float)y * deltaSpeed);
+        m_rot.z += ((float)r * deltaSpeed);
+        if (m_rot.x > static_cast<float>(3.14159265358979323846 / 2.0)) m_rot.x = static_cast<float>((3.14159265358979323846 / 2.0) - 0.0001);
+        if (m_rot.x < static_cast<float>(-3.14159265358979323846 / 2.0)) m_rot.x = static_cast<float>((-3.14159265358979323846 / 2.0) + 0.0001);
+    }
     void SetRot(const float p, const float y, const float r)
     {
         m_rot = MyMath::Vector3(p, y, r);
@@ -291,8 +436,13 @@ private:
         m_pMatrix.row1.x = p.element1;
         m_pMatrix.row2.y = p.element2;
         m_far = p.cam_far;
+        // Camera3D.cpp:61-71
+        const float yaw = m_rot.y;
+        m_staticForward = MyMath::Vector3(-std::sin(yaw), -std::cos(yaw), -std::cos(yaw));
+        m_staticRight = MyMath::Vector3(std::cos(yaw), -std::sin(yaw), -std::sin(yaw));
     }
     MyMath::Matrix m_inverse, m_pMatrix;
+    MyMath::Vector3 m_staticForward, m_staticRight;
     MyMath::Vector3 m_pos;
     MyMath::Vector3 m_rot = MyMath::Vector3(0.0f, 3.14159274101257324f, 0.0f); // Camera3D.h:62
     float m_far = 250.0f;

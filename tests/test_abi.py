@@ -202,4 +202,4 @@ def test_header_is_valid_c99_and_cxx():
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
                            os.path.join(U.ROOT, "examples", "headless_engine.cpp")])
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc,
-                           os.path.join(U.ROOT, "examples", "console_demo.cpp")])
+                           os.path.join(U.ROOT, "examples", "console_engine.cpp")])

@@ -3,7 +3,7 @@
 // raw-mode keyboard input where the reference polls Win32 key state, and PrintMachine's printer thread
 // (PrintMachine.cpp:257-306) writing each minimised frame to the terminal after an ANSI cursor-home.
 //
-//   console_engine [W H] [--mode 0..4] [--frames N] [--dt seconds] [--lockstep] [--no-spawn] [--no-status] [--trace FILE]
+//   console_engine [W H] [--mode 0..4] [--frames N] [--dt seconds] [--lockstep] [--no-spawn] [--no-status] [--trace FILE] [--keys-only]
 //
 // Keys (the reference's, as far as a terminal can deliver them -- there are no key-up events and no mouse, so a key
 // counts as held for the frame in which its byte arrives and the arrow keys stand in for mouse motion):
@@ -137,7 +137,7 @@ int main(int argc, char** argv)
     size_t W = 160, H = 50;
     int mode0 = BIT_ASCII, max_frames = -1; // the reference starts in BIT_ASCII (RayTracingManager.h:53)
     double fixed_dt = -1.0;
-    bool lockstep = false, spawn = true, status = true;
+    bool lockstep = false, spawn = true, status = true, keys_only = false;
     const char* trace_path = nullptr;
     int positional = 0;
     for (int i = 1; i < argc; i++) {
@@ -148,6 +148,7 @@ int main(int argc, char** argv)
         else if (a == "--lockstep") lockstep = true;
         else if (a == "--no-spawn") spawn = false;
         else if (a == "--no-status") status = false;
+        else if (a == "--keys-only") keys_only = true; // input check without a GPU: raw mode on, print each decoded key, quit on x / Esc / end of input
         else if (a == "--trace" && i + 1 < argc) trace_path = argv[++i];
         else if (a[0] != '-' && positional == 0) { W = std::strtoul(argv[i], nullptr, 10); positional++; }
         else if (a[0] != '-' && positional == 1) { H = std::strtoul(argv[i], nullptr, 10); positional++; }
@@ -159,6 +160,25 @@ int main(int argc, char** argv)
     if (W == 0 || H == 0 || mode0 < 0 || mode0 > 4) {
         std::fprintf(stderr, "bad size or mode\n");
         return 2;
+    }
+    if (keys_only) {
+        static const char* const names[] = {"none", "w", "a", "s", "d", "space", "shift", "up", "down", "left", "right", "mode0", "mode1", "mode2", "mode3",
+                                            "mode4", "quit", "eof", "other"};
+        Terminal term;
+        KeyReader keys;
+        std::printf("raw %d\n", term.active ? 1 : 0);
+        std::fflush(stdout);
+        for (;;) {
+            Key k = keys.next();
+            while (k == K_NONE) {
+                keys.fill(1000);
+                k = keys.next();
+            }
+            std::printf("key %s\n", names[k]);
+            std::fflush(stdout);
+            if (k == K_QUIT || k == K_EOF) break;
+        }
+        return 0;
     }
     std::FILE* trace = trace_path ? std::fopen(trace_path, "w") : nullptr;
     try {

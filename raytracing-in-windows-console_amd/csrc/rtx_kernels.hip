@@ -151,6 +151,70 @@ __device__ __forceinline__ V3 tile_plane(const Camera& c, uint32_t col0, uint32_
     return v3(0.0f, 0.0f, 0.0f);
 }
 
+// true when no pixel ray of the rectangle (columns [col0, col0+w), rows [row0, row0+h), half a pixel out, as for the
+// pyramids) can hit the bounded plane {n, num = Dot(planePos - origin, n), bounds xlo xhi zlo zhi}, so that the
+// workgroup may leave the plane out of its table.  Plane::Trace (Plane.cu:38-72) reports a hit iff dn < 0 (beyond
+// FLT_EPSILON), t = num / dn > 0 and the hit point lies strictly inside the bounds in x and z.
+//  * num >= 0: a ray with dn < 0 gets t <= 0 -- exactly, the fp32 quotient has the sign of its operands -- and every
+//    other ray is rejected on dn: no hit, whatever the rectangle.
+//  * Pixel directions are convex combinations of the four corner directions w_i, and w . n is linear: if it is
+//    positive at all corners (by more than 1e-5 |w||n|) every dn is positive: no hit.
+//  * If it is negative at all corners, every ray hits the unbounded plane and the hit points lie in the convex
+//    hull of the four corner hit points (central projection of a convex cone onto a plane that cuts all its rays).
+//    The plane is invisible when their bounding interval, widened by the worst rounding error of the per-pixel
+//    arithmetic, misses the bounds in x or in z.  That error: |dn| >= q = min |w_i . n| / max |w_i| over the cone,
+//    dn carries an absolute error below 4e-7, so t and the hit offset d t carry a relative error below
+//    4e-7 / q + 1e-6; the bound used is 2e-6 / q + 1e-5 of (|origin| + largest corner offset), and grazing
+//    rectangles (q < 1e-3) are kept.
+// Anything undecided (mixed signs, NaNs, degenerate matrices) keeps the plane.  Culling geometry, not reference
+// arithmetic: hardware rcp/sqrt.
+__device__ __forceinline__ bool plane_invisible(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, V3 n, float num, float4 bd)
+{
+    if (num >= 0.0f) {
+        return true;
+    }
+    const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
+    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
+    const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
+    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;
+    const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;
+    const float nn = dot(n, n);
+    bool away = true, facing = true;
+    float min_abs = __builtin_inff(), max_len2 = 0.0f;
+    float hx_lo = __builtin_inff(), hx_hi = -__builtin_inff(), hz_lo = __builtin_inff(), hz_hi = -__builtin_inff(), span_x = 0.0f, span_z = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const V3 wi = view_dir(c, (i == 1 || i == 2) ? x1 : x0, i >= 2 ? y1 : y0);
+        const float wn = dot(wi, n), len2 = dot(wi, wi);
+        const float eps = 1.0e-5f * __builtin_amdgcn_sqrtf(len2 * nn);
+        away = away && (wn > eps);
+        facing = facing && (wn < -eps);
+        min_abs = fminf(min_abs, fabsf(wn));
+        max_len2 = fmaxf(max_len2, len2);
+        const float si = num * __builtin_amdgcn_rcpf(wn); // > 0 where the corner faces the plane
+        const float dx = wi.x * si, dz = wi.z * si;
+        hx_lo = fminf(hx_lo, c.ox + dx);
+        hx_hi = fmaxf(hx_hi, c.ox + dx);
+        hz_lo = fminf(hz_lo, c.oz + dz);
+        hz_hi = fmaxf(hz_hi, c.oz + dz);
+        span_x = fmaxf(span_x, fabsf(dx));
+        span_z = fmaxf(span_z, fabsf(dz));
+    }
+    if (away) {
+        return true;
+    }
+    if (!facing) {
+        return false;
+    }
+    const float q = min_abs * __builtin_amdgcn_rsqf(max_len2 * nn);
+    if (!(q > 1.0e-3f)) {
+        return false;
+    }
+    const float rel = 2.0e-6f * __builtin_amdgcn_rcpf(q) + 1.0e-5f;
+    const float ex = rel * (fabsf(c.ox) + span_x) + 1.0e-30f, ez = rel * (fabsf(c.oz) + span_z) + 1.0e-30f;
+    return (hx_hi + ex <= bd.x) || (hx_lo - ex >= bd.y) || (hz_hi + ez <= bd.z) || (hz_lo - ez >= bd.w);
+}
+
 struct Best {
     float t;
     uint32_t k; // local sphere index, or 0xffffffff
@@ -470,6 +534,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
     __shared__ uint32_t s_cost[2];               // this tile's work estimate, summed over the waves; waves done
+    __shared__ uint32_t s_nplanes;               // planes of the LDS table this macro tile can see
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
@@ -618,16 +683,33 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     if (tid < 17u) {
         reinterpret_cast<uint32_t*>(s_ramp)[tid] = ramp4;
     }
-    if (tid < np_tab) {
-        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds
+    if (tid < 64u) {
+        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds.  Only
+        // the planes that some pixel ray of this macro tile can hit enter the table (plane_invisible), in table order.
         const V3 p = v3(pla.x, pla.y, pla.z), n = v3(plb.x, plb.y, plb.z);
         const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
         const float hw = pla.w * 0.5f, hh = plb.w * 0.5f;
-        s_plane[3 * tid + 0] = make_float4(n.x, n.y, n.z, num);
-        s_plane[3 * tid + 1] = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
-        s_plane[3 * tid + 2] = pld;
+        const float4 bounds = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
+#ifdef RTX_NO_PLANE_CULL // experiment builds: every plane enters the table
+        const bool listed = tid < np_tab;
+#else
+        // (from two planes on: with a single plane the test costs the workgroup what leaving the plane out saves --
+        // measured at C2, 19.9 vs 20.2 us per frame)
+        const bool listed = tid < np_tab && !(CULL && np >= 2u && !ABL(128u) && plane_invisible(cam, mcol0, mrow0, mw, mh, n, num, bounds));
+#endif
+        const unsigned long long m = __ballot(listed);
+        if (listed) {
+            const uint32_t at = (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
+            s_plane[3 * at + 0] = make_float4(n.x, n.y, n.z, num);
+            s_plane[3 * at + 1] = bounds;
+            s_plane[3 * at + 2] = pld;
+        }
+        if (tid == 0u) {
+            s_nplanes = (uint32_t)__popcll(m);
+        }
     }
     lds_barrier(); // list complete, tables visible
+    const uint32_t np_vis = (uint32_t)__builtin_amdgcn_readfirstlane(s_nplanes); // planes in the table
     STAMP(2);
 
     // ---- one pass per sub-tile.  (Drawing the waves' 64-pixel shares of the sub-tiles from a counter in LDS, so that a
@@ -728,7 +810,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
 
         // ---- planes: hoisted form from LDS (wave-uniform index: broadcast reads), Plane.cu:38-72
         uint32_t plane_q = 0xffffffffu; // winning plane, if a plane beats the best sphere
-        for (uint32_t q = 0; q < np_tab; q++) {
+        for (uint32_t q = 0; q < np_vis; q++) {
             const float4 pn = s_plane[3 * q + 0];
             const float dn = ray.d.x * pn.x + ray.d.y * pn.y + ray.d.z * pn.z;
             if (dn > 0.0f || fabsf(dn - 0.0f) < 1.1920928955078125e-7f) {

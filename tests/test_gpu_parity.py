@@ -612,3 +612,49 @@ def test_a_million_spheres_and_scratch_proportional_to_the_scene(R):
         free1 = torch.cuda.mem_get_info()[0]
         assert O.fnv1a64(got5) == U.load_golden()["C5_RGB_ASCII"]["frame_fnv1a64"]
         assert free0 - free1 <= 8 * 1024 * 1024, "two-level scratch for C5 took %.1f MB" % ((free0 - free1) / 1e6)
+
+
+# ---------------------------------------------------------------- per-tile plane visibility (plane_invisible)
+
+@pytest.mark.parametrize("seed", range(8))
+def test_planes_left_out_of_a_tile_are_never_hit_there(R, ctx, seed):
+    """The culling kernels leave a plane out of a macro tile's table when no pixel ray of the tile can hit it (facing
+    away, behind the origin, or its bounded extent off the tile).  Random bounded planes of every orientation --
+    grazing, behind the camera, containing the camera, tiny and huge -- and random cameras, all tile shapes: the
+    binned frames must equal the oracle's (and the brute kernel's, which tests every plane at every pixel)."""
+    rng = np.random.default_rng(31000 + seed)
+    w, h = [(400, 150), (333, 97), (640, 200), (129, 257), (1280, 90), (257, 129), (512, 512), (97, 403)][seed]
+    pos = rng.uniform(-20, 20, 3)
+    rot = (float(rng.uniform(-1.4, 1.4)), float(rng.uniform(0, 6.28)), 0.0)
+    p = R.camera_params(w, h, [float(v) for v in pos], rot)
+    ctx.scene_clear()
+    sc = O.Scene()
+    for i in range(14):
+        kind = i % 7
+        centre = pos + rng.normal(0, 1, 3) * rng.choice([3.0, 30.0, 120.0])
+        nrm = rng.normal(0, 1, 3)
+        if kind == 0:
+            nrm = np.array([0.0, 1.0, 0.0])                       # floors and ceilings
+        elif kind == 1:
+            nrm = np.array([0.0, -1.0, 0.0])
+        elif kind == 2:
+            centre = pos + np.array([0.0, -1e-3, 0.0])            # the camera (almost) on the plane
+            nrm = np.array([0.0, 1.0, 0.0])
+        elif kind == 3:
+            nrm = np.array([1.0, rng.normal(0, 0.02), 0.0])       # walls: bounded in x by a thin slab
+        width, height = float(rng.choice([0.5, 8.0, 60.0, 500.0])), float(rng.choice([0.5, 8.0, 60.0, 500.0]))
+        col = [float(v) for v in np.floor(rng.uniform(1, 256, 3))]
+        args = ([float(v) for v in centre], [float(v) for v in nrm], col, width, height)
+        ctx.add_plane(*args)
+        sc.add_plane(*args)
+        if i % 3 == 0:
+            sph = ([float(v) for v in centre + rng.normal(0, 2, 3)], float(rng.uniform(0.5, 4.0)), col)
+            ctx.add_sphere(sph[1], sph[0], sph[2])
+            sc.add_sphere(sph[1], sph[0], sph[2])
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
+    assert int((want.reshape(h, w, 20)[:, :w - 1, 2] == ord("3")).sum()) > 0, "the test scene shows nothing"
+    for kernel, tile, sub in (("brute", 0, 0), ("binned", 0, 0), ("binned", 2, 1), ("binned", 6, 4), ("binned", 4, 16), ("binned", 3, 8)):
+        set_kernel(R, ctx, kernel, tile, sub)
+        got = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(got, want, O.RGB_ASCII, w, "planes seed %d %s tile %d sub %d" % (seed, kernel, tile, sub))
+    set_kernel(R, ctx, "auto")

@@ -535,6 +535,11 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
     __shared__ uint32_t s_cost[2];               // this tile's work estimate, summed over the waves; waves done
     __shared__ uint32_t s_nplanes;               // planes of the LDS table this macro tile can see
+    // What only the rare paths of the pass loop need (the overflow fallback: the item list and the pyramid; planes
+    // beyond the table: the plane arrays) is parked here and read back inside those paths, so that it does not
+    // occupy scalar registers -- or spill slots that every pass reloads -- for the whole loop.
+    __shared__ unsigned long long s_rare_ptr[4]; // item list, pl_a, pl_b, pl_od
+    __shared__ uint32_t s_rare_count;            // items
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lw = a.tile_log2w;
@@ -589,6 +594,13 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     }
     if (ABL(1u)) items.count = 0u;
     const uint32_t ns = items.count;
+    if (tid == 0u) {
+        s_rare_ptr[0] = (unsigned long long)(uintptr_t)items.list;
+        s_rare_ptr[1] = (unsigned long long)(uintptr_t)a.pl_a;
+        s_rare_ptr[2] = (unsigned long long)(uintptr_t)a.pl_b;
+        s_rare_ptr[3] = (unsigned long long)(uintptr_t)a.pl_od;
+        s_rare_count = items.count;
+    }
     // first staging step's loads go out before anything else
     uint32_t k0, k1;
     float4 g0 = load_item(items, tid, k0), g1 = load_item(items, kThreads + tid, k1);
@@ -732,7 +744,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         Best b;
         b.t = kNoHit;
         b.k = 0xffffffffu;
-        uint32_t scanned = overflow ? ns : total; // candidates this wave tests in this pass
+        uint32_t scanned = total; // candidates this wave tests in this pass (the overflow path: at least that many)
         if (!overflow) {
             bool refined = false;
             if (REFINE && total > 8u) {
@@ -781,16 +793,31 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
             // the list into the best hit whenever it fills.
             lds_barrier();
+            // the item list and the pyramid, back from LDS (the compiler barrier keeps the reads in this branch instead
+            // of hoisting them out of the pass loop)
+            asm volatile("" ::: "memory");
+            Items its;
+            its.geom = a.sph_geom;
+            its.list = reinterpret_cast<const uint32_t*>((uintptr_t)s_rare_ptr[0]);
+            its.count = s_rare_count;
+            const uint32_t nit = its.count;
+            TileFrustum fr2;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                fr2.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
+                fr2.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 1])));
+                fr2.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
+            }
             uint32_t tot = 0, par = 0;
             uint32_t i0, i1;
-            float4 h0 = load_item(items, tid, i0), h1 = load_item(items, kThreads + tid, i1);
-            for (uint32_t base = 0; base < ns; base += kChunk, par ^= 1u) {
+            float4 h0 = load_item(its, tid, i0), h1 = load_item(its, kThreads + tid, i1);
+            for (uint32_t base = 0; base < nit; base += kChunk, par ^= 1u) {
                 const float4 c0 = h0, c1 = h1;
                 const uint32_t j0 = i0, j1 = i1;
-                h0 = load_item(items, base + kChunk + tid, i0);
-                h1 = load_item(items, base + kChunk + kThreads + tid, i1);
-                tot = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
-                if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= ns) {
+                h0 = load_item(its, base + kChunk + tid, i0);
+                h1 = load_item(its, base + kChunk + kThreads + tid, i1);
+                tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
+                if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
                     lds_barrier();
                     scan_candidates(ray, s_rec, s_idx, tot, b);
                     tot = 0;
@@ -832,18 +859,24 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 plane_q = q;
             }
         }
-        for (uint32_t q = np_tab; q < np; q++) { // beyond the LDS table: the direct form
-            const float4 pa = a.pl_a[q]; // px py pz width
-            const float4 pb = a.pl_b[q]; // nx ny nz height
+        if (np > np_tab) { // beyond the LDS table (more than 16 planes): the direct form, array pointers back from LDS
+            asm volatile("" ::: "memory");
+            const float4* rare_pl_a = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[1]);
+            const float4* rare_pl_b = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[2]);
+            const float4* rare_pl_od = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[3]);
+          for (uint32_t q = np_tab; q < np; q++) {
+            const float4 pa = rare_pl_a[q]; // px py pz width
+            const float4 pb = rare_pl_b[q]; // nx ny nz height
             float t;
             if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
-                const uint32_t gi = __float_as_uint(a.pl_od[q].w);
+                const uint32_t gi = __float_as_uint(rare_pl_od[q].w);
                 if (t < b.t || (t == b.t && gi < (plane_q != 0xffffffffu ? best_gidx : (sphere_hit_any ? __float_as_uint(wod.w) : 0xffffffffu)))) {
                     b.t = t;
                     best_gidx = gi;
                     plane_q = q;
                 }
             }
+        }
         }
 
         // ---- shade the winner (RayTracing.cu:123-157).  Values of a missed pixel are never encoded.
@@ -860,8 +893,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     pb = s_plane[3u * plane_q + 0u];
                     pd = s_plane[3u * plane_q + 2u];
                 } else {
-                    pb = a.pl_b[plane_q];
-                    pd = a.pl_od[plane_q];
+                    asm volatile("" ::: "memory");
+                    pb = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[2])[plane_q];
+                    pd = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[3])[plane_q];
                 }
                 n0 = v3(pb.x, pb.y, pb.z);
                 od = v3(pd.x, pd.y, pd.z);

@@ -10,22 +10,22 @@
  * normalisation kept).  Reference citations are file:line under
  * /root/reference/ConsoleProject/.
  *
- * Pinning status: the reference has no tests or golden vectors.
- * It also cannot be compiled in this image: every source includes pch.h which needs
- * <windows.h> and <cuda_runtime.h> (pch.h:4,41), and writing stand-ins for headers the
- * image lacks is not permitted.  The oracle is therefore pinned by the known answers
- * SURVEY.md section 8(c) recorded from the reference's own sources: ten FNV-1a-64 hashes
- * of the full 20*W*H buffer (default scene, five modes, 400x150 and 1920x1080) and
- * the exhaustive 2^24-input hash of ansi256_from_rgb.  tests/test_oracle_pins.py
- * checks all eleven.  They cover ray generation, both intersection tests, shading, the
- * record encoders and the xterm-256 mapper (everything orc_render_rows runs), and
- * orc_camera_params through the survey's recorded default-camera values.
+ * PARITY UNPINNED.  The reference holds no tests, fixtures or golden vectors, and it
+ * cannot be compiled in this image: every source includes pch.h, which needs <windows.h> and <cuda_runtime.h>
+ * (pch.h:4,41), and writing stand-ins for headers the image lacks is not permitted.  So there is no output of the
+ * reference itself to check this restatement against.  What exists is corroboration, not a pin: SURVEY.md section
+ * 8(c) records eleven known answers that the survey session computed from the reference's sources (with stand-in
+ * headers, and with an FNV-1a offset basis that had to be recovered from the values: see ORC_FNV_OFFSET_SURVEY below)
+ * -- ten FNV-1a-64 hashes of the full 20*W*H buffer (default scene, five modes, 400x150 and 1920x1080) and the
+ * exhaustive 2^24-input hash of ansi256_from_rgb.  tests/test_oracle_pins.py reproduces all eleven.  They touch ray
+ * generation, both intersection tests, shading, the record encoders and the xterm-256 mapper (everything
+ * orc_render_rows runs) and, through the survey's recorded default-camera values, orc_camera_params.
  *
- * PARITY UNPINNED: orc_minimize (RayTracingManager.cu:167-319) and orc_update_objects
- * (RayTracingManager.cu:10-44, Sphere.cu:15-23).  Neither the reference nor the survey
- * holds an output of these two for any input, so the restatements are anchored only on
- * the source text they cite and on what the tests check (tests/test_oracle_minimize.py: a second,
- * array-level statement of the same rule on real frames, edge cases and newline invariants).
+ * Not even corroborated: orc_minimize (RayTracingManager.cu:167-319) and orc_update_objects
+ * (RayTracingManager.cu:10-44, Sphere.cu:15-23).  Neither the reference nor the survey holds an output of these two
+ * for any input, so the restatements are anchored only on the source text they cite and on what the tests check
+ * (tests/test_oracle_minimize.py: a second, array-level statement of the same rule on real frames, edge cases and
+ * newline invariants).
  */
 #ifndef RTX_ORACLE_H
 #define RTX_ORACLE_H

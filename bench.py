@@ -122,9 +122,10 @@ def main():
     ap.add_argument("--frames-per-root", type=int, default=0, help="N>1, --exchange compact: M (0 = 8/4/4 for 2/4/8 GPUs; 8 with --root fixed)")
     ap.add_argument("--graphs", type=int, default=1, help="N>1, --exchange compact: record a round's slab launches (and its expansions) as HIP graphs (0 = off)")
     ap.add_argument("--latency", action="store_true", help="N>1, --exchange compact: also stamp every frame's completion and report queue-to-complete latency")
-    ap.add_argument("--frames-in-flight", type=int, default=4,
-                    help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers "
-                         "(1 = strictly one launch after the other, the form the rocprof summaries are taken in)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers (default 4; "
+                         "1 = strictly one launch after the other, the form the rocprof summaries are taken in).  "
+                         "N>1: render streams the slab launches of a round are spread over (default 2 for N<=2, else 4)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed, uncounted run-in before the warm-up steps so that the GPU is at its running clocks "
                          "(N>1: the equivalent number of frames, fixed so that all ranks agree)")
@@ -175,6 +176,8 @@ def main():
 
     ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)
     ctx.synchronize()
+    if args.frames_in_flight <= 0:
+        args.frames_in_flight = 4 if (not distributed or world > 2) else 2
     K, Wm = args.steps, args.warmup
     bounds = sharding.row_bounds(H, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
@@ -310,7 +313,14 @@ def main():
             kernel_ms = median(singles)
     else:
         import torch.distributed as dist
-        stream = torch.cuda.current_stream()
+        # The loop runs on a stream of its own, made torch's current stream: the collectives are ordered after it, and
+        # its handle is not 0.  (torch's default stream has handle 0, which the C ABI reads as "the context's own
+        # stream" / "no stream to join": with it neither rtx_submit_slabs' fork/join nor a graph capture would touch
+        # the stream the exchange is queued on.  Round 1's loop did exactly that; its frames only looked right because
+        # every frame of a bench run is the same frame.  The check rounds below would now catch it.)
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        assert stream.cuda_stream != 0
         if args.exchange in ("compact", "rounds"):
             # Frames in rounds of M*N, frame m*N+j of a round assembled on rank j, ONE all-to-all per round.  The
             # slab launches of a round go to F streams forked from / joined into torch's current stream (inside
@@ -444,8 +454,6 @@ def main():
             exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
         final = None
         timing = {"method": "wall clock around exactly K frames, barrier + synchronize on both sides, MAX over ranks", "repeats": 1}
-        if args.exchange in ("compact", "rounds") and latency is not None:
-            timing["frame_latency"] = latency
         dist_verified = None
         if not args.no_verify:
             # byte check of the last assembled frame, outside the timed region: its root hashes it (SHA-256 of the
@@ -463,6 +471,67 @@ def main():
             flag = torch.tensor([code], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             dist_verified = {0: False, 1: True}.get(int(flag.item()))   # None: no rank compared anything
+        # ---- check rounds, outside the timed region: is every frame that arrives on a root the frame its camera
+        # renders?  (a) the send buffers are poisoned and one more round goes through the very path that was timed
+        # (graph replays included): a slab that was not rendered again, or exchanged before it was rendered, shows as
+        # poison; (b) a round in which every frame has its own camera, queued launch by launch: a slab that lands in the
+        # wrong frame or on the wrong root shows.  Each root compares its frames on the GPU with the whole frame it
+        # renders itself for the same camera.
+        rounds_ok = None
+        if args.exchange in ("compact", "rounds") and not args.no_verify:
+            code = 1
+            try:
+                qn = q0 + n_rounds
+                tmp = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+
+                def frame_is(i, p_i):
+                    ctx.render_rows(p_i, mode, 0, H, d_out=tmp.data_ptr(), out_row_base=0, stream=stream.cuda_stream,
+                                    flags=0 if mode >= R.RGB_ASCII else R.RENDER_ZERO_TAIL)
+                    torch.cuda.synchronize()
+                    return bool(torch.equal(pipe.frame(i)[:S * W * H], tmp[:S * W * H]))
+
+                for b in range(pipe.nbuf):
+                    pipe.send[b].fill_(0xEE)
+                for r in range(pipe.nbuf):
+                    pipe.round(qn + r, RF, render_round)
+                pipe.drain()
+                torch.cuda.synchronize()
+                for r in range(pipe.nbuf):
+                    for f in range(RF):
+                        i = (qn + r) * RF + f
+                        if pipe.root_of(i) == rank and not frame_is(i, params):
+                            sys.stderr.write("bench.py: rank %d: frame %d of a poisoned round differs from the frame rendered in one piece\n" % (rank, i))
+                            code = 0
+                qn += pipe.nbuf
+                cams = [R.camera_params(W, H, pos=(0.03 * f, 0.01 * f, 0.0), rot=(0.0, float(np.float32(np.pi)) + 0.002 * f, 0.0)) for f in range(RF)]
+
+                def render_round_cams(q, b, nframes):
+                    if rows:
+                        ctx.submit_slabs(cams[:nframes], mode, row0, rows, [pipe.unit(b, f).data_ptr() for f in range(nframes)], row0,
+                                         [rstreams[f % F].cuda_stream for f in range(nframes)], after=stream.cuda_stream,
+                                         flags=R.RENDER_COMPACT if compact else 0)
+
+                pipe.round(qn, RF, render_round_cams)
+                pipe.drain()
+                torch.cuda.synchronize()
+                for f in range(RF):
+                    i = qn * RF + f
+                    if pipe.root_of(i) == rank and not frame_is(i, cams[f]):
+                        sys.stderr.write("bench.py: rank %d: frame %d (own camera) differs from the frame rendered in one piece\n" % (rank, i))
+                        code = 0
+            except Exception as exc:
+                sys.stderr.write("bench.py: check rounds failed on rank %d: %r\n" % (rank, exc))
+                code = 0
+            flag = torch.tensor([code], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            rounds_ok = bool(flag.item())
+            if rounds_ok is False:
+                dist_verified = False
+            timing["check_rounds"] = {"passed": rounds_ok,
+                                      "what": "after the timed region: %d round(s) through the timed path with poisoned send buffers, one round with a camera "
+                                              "per frame; every root compares its frames with the same frames rendered in one piece" % pipe.nbuf}
+        if args.exchange in ("compact", "rounds") and latency is not None:
+            timing["frame_latency"] = latency
         # per-rank kernel time, measured apart from the pipeline, for the roofline object
         ctx.synchronize()
         ctx.timer_start()

@@ -150,14 +150,20 @@ struct Camera {
 //
 // sphere_reject: the miss test on the hoisted terms otc = o - c and cc = Dot(otc,otc) - r*r
 // (ray-independent for primary rays, which all share the origin).  The reference evaluates
-// disc = b*b - fourA*cc with b = 2*s, fourA = 4*a.  Scaling by powers of two is exact, so
-// disc == 4 * (s*s - a*cc) bit for bit (barring subnormal s*s or a*cc, which needs
-// |o-c| or r below 1e-18); the sign test therefore runs on s*s - a*cc, one multiply fewer.
+// disc = b*b - fourA*cc with b = 2*s, fourA = 4*a.  Scaling by powers of two commutes with rounding while
+// nothing overflows or goes subnormal, so there disc == 4 * (s*s - a*cc) bit for bit and the sign test
+// runs on q = s*s - a*cc, one multiply fewer.  The rejection is only taken when q < -1e-30: then at least one
+// of the two products is a normal number of that size, a subnormal partner moves neither sum by more than
+// 1e-44, and disc is negative too; the sliver -1e-30 <= q < 0 goes on to sphere_hit, which evaluates the literal
+// discriminant.  Overflow (|s| > 9.2e18, or a*cc near 1e38) makes disc +-inf or NaN where q is finite, but every
+// such case ends in a miss on both routes: disc = -inf is a reject, +inf gives t2 = -inf, NaN gives NaN roots
+// that no comparison accepts -- and whenever q does not reject, sphere_hit runs the reference's own arithmetic.
+// So the outcome equals the reference's for every input (tests: scenes scaled by 1e18 and 1e-18).
 __device__ __forceinline__ bool sphere_reject(const Ray& r, float ox, float oy, float oz, float cc, float& s)
 {
     s = r.d.x * ox + r.d.y * oy + r.d.z * oz;
     const float q = s * s - r.a * cc;
-    return q < 0.0f;
+    return q < -1.0e-30f;
 }
 
 // sphere_hit: the literal reference arithmetic from the discriminant on; true with t set on a hit.

@@ -658,3 +658,30 @@ def test_planes_left_out_of_a_tile_are_never_hit_there(R, ctx, seed):
         got = ctx.render_to_host(p, R.RGB_ASCII)
         assert_same(got, want, O.RGB_ASCII, w, "planes seed %d %s tile %d sub %d" % (seed, kernel, tile, sub))
     set_kernel(R, ctx, "auto")
+
+
+# ---------------------------------------------------------------- extreme magnitudes
+
+@pytest.mark.parametrize("scale", [1e18, 3e18, 1e-18, 1e-16, 1e10, 1e-10])
+def test_scenes_at_extreme_scales(R, ctx, scale):
+    """The kernels reject a sphere on s*s - a*cc instead of the reference's b*b - 4a*cc (one multiply fewer); the two
+    agree bit for bit except where a product overflows or goes subnormal (|o - c| around 1e19 or 1e-19).  There the
+    rejection is only taken when it is certain, and otherwise the literal arithmetic decides: the whole scene scaled to
+    those magnitudes (camera far plane and light stay where they are, as in the reference) must still give the oracle's
+    frame from every kernel.  Also exercises the culling margins with infinite and NaN intermediates."""
+    rng = np.random.default_rng(12)
+    w, h = 200, 75
+    p = R.camera_params(w, h, (0.0, 0.0, 0.0), (0.05, 3.1, 0.0))
+    n = 120
+    centres = np.stack([rng.uniform(-60, 60, n), rng.uniform(-20, 20, n), rng.uniform(20, 200, n)], axis=1) * scale
+    radii = rng.uniform(2, 15, n) * scale
+    cols = np.floor(rng.uniform(1, 256, (n, 3)))
+    sph = np.concatenate([centres, radii[:, None], cols], axis=1).astype(np.float32)
+    pl = np.array([[0, -30 * scale, 125 * scale, 0, 1, 0, 100, 100, 100, 3000 * scale, 250 * scale]], dtype=np.float32)
+    ctx.set_scene(sph, pl)
+    want = O.render(U.oracle_params(p), O.Scene.from_arrays(sph, pl), O.RGB_ASCII, threads=4)
+    for kernel, two in (("brute", 0), ("binned", 0), ("binned", 1)):
+        set_kernel(R, ctx, kernel, two_level=two)
+        got = ctx.render_to_host(p, R.RGB_ASCII)
+        assert_same(got, want, O.RGB_ASCII, w, "scale %g %s two-level %d" % (scale, kernel, two))
+    set_kernel(R, ctx, "auto")

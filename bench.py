@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--subtiles", type=int, default=0)
     ap.add_argument("--two-level", type=int, default=-1, help="-1 auto, 0 off, 1 on, 2 on with block binning")
     ap.add_argument("--refine", type=int, default=-1)
-    ap.add_argument("--tile-order", type=int, default=-1, help="heaviest-first dispatch of the macro tiles: -1 library default, 0 off, k refresh period")
+    ap.add_argument("--tile-order", type=int, default=-2, help="heaviest-first dispatch of the macro tiles: -2 library default (auto), -1 auto, 0 off, k refresh period")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="(default) check the last frame against the golden hash, outside the timed region")
@@ -171,7 +171,7 @@ def main():
     ctx.set_option(R.OPT_SUBTILES, args.subtiles)
     ctx.set_option(R.OPT_TWO_LEVEL, args.two_level)
     ctx.set_option(R.OPT_REFINE, args.refine)
-    if args.tile_order >= 0:
+    if args.tile_order >= -1:
         ctx.set_option(R.OPT_TILE_ORDER, args.tile_order)
 
     ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)

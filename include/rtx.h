@@ -84,11 +84,13 @@ enum rtx_option {
     RTX_OPT_CELL_CAPACITY = 7, /* entries per coarse-cell list of that pre-pass; 0 = auto (4 * spheres / cells + 1024, so that the
                                * scratch is O(spheres)).  A cell whose list does not fit falls back to the whole scene: slower,
                                * the same frame */
-    RTX_OPT_TILE_ORDER = 6,   /* binned kernel: dispatch the macro tiles heaviest first, from the work estimates the previous frames
-                               * of the same tile grid left behind (speed only: the frame is the same in any order).  0 = frame
-                               * order (default: measured gain 1.5 % for one 1080p launch alone, none with frames in flight, and a
-                               * 10 % loss at 8K, where it scatters the record writes); k > 0 = derive the order after the first
-                               * two frames of a grid, then after every k-th */
+    RTX_OPT_TILE_ORDER = 6,   /* binned kernel: dispatch the macro tiles heaviest first and dealt evenly over the CUs, from the work
+                               * estimates the previous frames of the same tile grid left behind (speed only: the frame is the same
+                               * in any order).  -1 = auto (default): on for tile grids whose workgroups are all resident at once
+                               * (then 5 or 6 sub-tiles per workgroup are chosen to make that so, e.g. at 1080p: one launch alone
+                               * 29.3 -> 28.1 us), off for larger grids, where it gains nothing and at 8K costs 10 % by separating
+                               * tiles that share 128-byte lines; 0 = frame order; k > 0 = on for every grid, order derived after
+                               * the first two frames of a grid and then after every k-th (auto: 16) */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup; otherwise it stays off) */
 };

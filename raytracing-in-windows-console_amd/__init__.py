@@ -214,6 +214,11 @@ class Context:
     def set_option(self, opt, value):
         self._check(lib().rtx_set_option(self._h, opt, value))
 
+    def get_option(self, opt):
+        v = C.c_int64(0)
+        self._check(lib().rtx_get_option(self._h, opt, C.byref(v)))
+        return v.value
+
     # -- scene (Scene3D::CreateSphere / CreatePlane, Scene3D.cpp:36-86)
     def scene_clear(self):
         self._check(lib().rtx_scene_clear(self._h))

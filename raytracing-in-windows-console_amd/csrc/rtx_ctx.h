@@ -71,7 +71,8 @@ struct rtx_ctx {
         uint64_t frames = 0;         // traces of this grid since the last reset
     };
     std::vector<TileOrder> tile_orders;
-    int64_t opt_tile_order = 0;     // 0 = off (default); k = re-derive the order after the 1st and 2nd frame of a grid, then every k-th
+    int64_t opt_tile_order = -1;    // -1 = auto (grids of one dispatch round, period 16), 0 = off, k = on: re-derive the order after
+                                    // the 1st and 2nd frame of a grid, then every k-th
     int n_cu = 0;                   // compute units of the device
 
     // events of rtx_submit_slabs' fork/join: one for `after`, one per distinct render stream seen

@@ -510,23 +510,25 @@ def _render_into_poisoned_buffer(R, ctx, p, mode, buf):
     return buf.cpu().numpy()
 
 
-@pytest.mark.parametrize("period", [1, 3])
+@pytest.mark.parametrize("period", [-1, 1, 3])
 def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     """The order the workgroups take the macro tiles in is derived from the previous frames' work estimates; any
-    permutation must give the same bytes.  C2 over several frames (order refreshed after every frame / every third),
-    every frame against the golden hash."""
+    permutation must give the same bytes.  C2 over several frames (order refreshed after every frame / every third /
+    the library's default: five sub-tiles per workgroup so the grid is one dispatch round, refreshed after frames 1, 2
+    and 16), every frame against the golden hash."""
     import torch
     p, sph, pl = R.config_inputs("C2")
     ctx.set_scene(sph, pl)
     W, H = int(p.x), int(p.y)
     buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
     gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
-    set_kernel(R, ctx, "binned", tile_order=period)
-    for i in range(7):
+    assert ctx.get_option(R.OPT_TILE_ORDER) == -1   # the default: auto
+    set_kernel(R, ctx, "auto" if period < 0 else "binned", tile_order=period)
+    for i in range(18 if period < 0 else 7):
         assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold, "frame %d" % i
     set_kernel(R, ctx, "binned", tile_order=0)
     assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold
-    set_kernel(R, ctx, "auto", tile_order=16)
+    set_kernel(R, ctx, "auto", tile_order=-1)
 
 
 def test_tile_order_with_a_moving_camera_changing_grids_and_slabs(R, ctx):
@@ -554,7 +556,7 @@ def test_tile_order_with_a_moving_camera_changing_grids_and_slabs(R, ctx):
             ctx.render_rows(p, R.RGB_ASCII, r0, r1 - r0, d_out=buf.data_ptr(), out_row_base=0)
         ctx.synchronize()
         assert_same(buf.cpu().numpy()[:20 * w * h], want, R.RGB_ASCII, w, "tile order, slabs, step %d" % step)
-    set_kernel(R, ctx, "auto", tile_order=16)
+    set_kernel(R, ctx, "auto", tile_order=-1)
 
 
 # ---------------------------------------------------------------- compact coarse-cell lists (rtx_bin_cells)

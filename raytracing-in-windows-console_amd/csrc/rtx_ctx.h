@@ -64,7 +64,13 @@ struct rtx_ctx {
     struct TileOrder {
         hipStream_t stream = nullptr;
         uint32_t* cost = nullptr;
-        uint32_t* order = nullptr;
+        uint32_t* order = nullptr;   // two orders of `cap` tiles: the one in use (cur) and the one a balancing pass writes
+        float* factor = nullptr;     // per-tile correction of the estimate (rtx_balance_tiles)
+        bool have_factor = false;
+        int cur = 0;
+        int pending = 0;             // 0 = none; 1 = a balancing pass was queued after the last launch; 2 = ... before the last launch
+        hipStream_t aux = nullptr;   // the balancing passes' stream
+        hipEvent_t ev_rec = nullptr, ev_done = nullptr;
         size_t cap = 0;              // tiles the buffers hold
         uint64_t key[3] = {0, 0, 0};
         bool have_order = false;

@@ -50,8 +50,10 @@ struct KArgs {
     uint32_t cell_cap;        // entries per cell list
     // Heaviest-first dispatch (speed only; any permutation of the macro tiles renders the same frame): tile_order[b] =
     // bx | by << 16 of the macro tile that workgroup b (linear block index, x fastest) renders, built by
-    // rtx_order_tiles from tile_cost, the work estimate every workgroup of an earlier launch left for its tile.
-    // Either may be nullptr (identity order / no estimate wanted).
+    // rtx_order_tiles / rtx_balance_tiles from tile_cost, the work estimate every workgroup of an earlier launch left
+    // for its tile: tile_cost[tile], followed by the workgroups' start and end times (100 MHz clock) by dispatch
+    // position: tile_cost[n_tiles + b], tile_cost[2 n_tiles + b].  Either may be nullptr (identity order / no estimate
+    // wanted).
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     uint8_t* out;             // records of row out_row_base start here
@@ -87,5 +89,11 @@ int rtx_k_launch_bin_cells(const KArgs* a, unsigned splits, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 // tile_cost[n_tiles] (grid gx wide) -> tile_order[n_tiles], heaviest first, dealt over n_cu compute units so that the
 // workgroups each unit receives in the first dispatch round (blocks c, c + n_cu, c + 2 n_cu, ...) carry equal work.
+// The same for a grid whose workgroups are all resident at once (n_tiles <= 2048, n_cu <= 1024): tile_cost holds 3 n_tiles
+// words (estimates by tile; start and end times by dispatch position, as the trace kernel leaves them), factor[n_tiles]
+// the per-tile corrections carried from launch to launch, prev_order the order the times were taken under (NULL: frame
+// order; may be tile_order itself).
+int rtx_k_launch_balance_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, const uint32_t* prev_order, float* factor,
+                               int have_factor, int have_times, uint32_t* tile_order, void* stream);
 int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round, uint32_t* tile_order, void* stream);
 }

@@ -17,6 +17,7 @@
 #include "rtx_device.hpp"
 #include "rtx_kernels.h"
 
+#include <cstdio>
 #include <cstdlib>
 
 namespace rtx {
@@ -354,10 +355,12 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
 }
 
 // Exact tests of one ray against the candidate list (index is wave-uniform: LDS broadcast reads).
-__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, uint32_t i, Best& best)
+__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, uint32_t i, Best& best, uint32_t& slow)
 {
     float s;
-    if (!sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s)) {
+    const bool rejected = sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s);
+    slow += __ballot(!rejected) != 0ull ? 1u : 0u; // candidates some lane of this wave takes to the exact test
+    if (!rejected) {
         ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
         float t;
         if (sphere_hit(ray, s, sr.w, t)) {
@@ -372,10 +375,10 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
 
 // (Requesting the next record one test ahead -- one or two records in flight -- was measured and dropped: 1-2 %
 // slower; with 6 waves per SIMD the LDS latency of the broadcast read is already hidden.)
-__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best)
+__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best, uint32_t& slow)
 {
     for (uint32_t i = 0; i < total; i++) {
-        test_candidate(ray, s_rec[i], s_idx, i, best);
+        test_candidate(ray, s_rec[i], s_idx, i, best, slow);
     }
 }
 
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
     __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
-    __shared__ uint32_t s_cost[2];               // this tile's work estimate, summed over the waves; waves done
+    __shared__ uint32_t s_cost[3];               // this tile's work estimate, summed over the waves; waves done; start time
     __shared__ uint32_t s_nplanes;               // planes of the LDS table this macro tile can see
     // What only the rare paths of the pass loop need (the overflow fallback: the item list and the pyramid; planes
     // beyond the table: the plane arrays) is parked here and read back inside those paths, so that it does not
@@ -616,6 +619,11 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     if (tid == 0u) {
         s_cost[0] = 0u;
         s_cost[1] = 0u;
+#ifndef RTX_NO_START_STAMP
+        if (a.tile_cost != nullptr) {
+            s_cost[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock per XCD: when this workgroup started
+        }
+#endif
     }
     if (tid < mw) {
         // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
@@ -728,6 +736,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // wave whose pixels miss everything moves on while its neighbour shades, was measured and dropped: +6 % per frame --
     // profiles/r02_c_single_launch_experiments.md.)
     uint32_t wcost = 0; // this wave's work estimate for the heaviest-first order (wave-uniform)
+#ifdef RTX_ABLATE
+    unsigned long long wfeat = 0; // diagnostic: slow-path entries, passes with a hit, passes, candidates, passes with a plane hit
+#endif
     const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
 #pragma unroll 1
     for (uint32_t j = 0; j < nsub; j++) {
@@ -745,6 +756,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         b.t = kNoHit;
         b.k = 0xffffffffu;
         uint32_t scanned = total; // candidates this wave tests in this pass (the overflow path: at least that many)
+        uint32_t slow = 0;        // ... and how many of them reach the exact test
         if (!overflow) {
             bool refined = false;
             if (REFINE && total > 8u) {
@@ -782,12 +794,12 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
                     for (uint32_t q = 0; q < cnt; q++) {
                         const uint32_t i = s_wlist[wave][q];
-                        test_candidate(ray, s_rec[i], s_idx, i, b);
+                        test_candidate(ray, s_rec[i], s_idx, i, b, slow);
                     }
                 }
             }
             if (!refined) {
-                if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b);
+                if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b, slow);
             }
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
                     lds_barrier();
-                    scan_candidates(ray, s_rec, s_idx, tot, b);
+                    scan_candidates(ray, s_rec, s_idx, tot, b, slow);
                     tot = 0;
                 }
             }
@@ -920,6 +932,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         wcost += kCostPass + kCostCandidate * scanned + (__ballot(in_frame && distance <= cam.far) != 0ull ? kCostShaded : 0u);
         STAMP(3 + (j < 9u ? j : 9u));
 #ifdef RTX_ABLATE
+        wfeat += ((unsigned long long)slow << 20) | ((__ballot(in_frame && distance <= cam.far) != 0ull ? 1ull : 0ull) << 32) | (1ull << 36) |
+                 ((unsigned long long)scanned << 40) | ((__ballot(plane_q != 0xffffffffu) != 0ull ? 1ull : 0ull) << 52);
         if (a.stamps && threadIdx.x == 0) {
             unsigned long long rt;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
@@ -928,13 +942,33 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         }
 #endif
     }
+#ifdef RTX_ABLATE
+    // light stamps: every wave leaves its SIMD (HW_ID), its end time and its work estimate in slots 0-3, 4-7, 8-11
+    if (a.stamps && (a.ablate & 0x8000u) && (threadIdx.x & 63u) == 0u) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long rt;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
+        unsigned long long* slot = a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+        slot[threadIdx.x >> 6] = hwid;
+        slot[4 + (threadIdx.x >> 6)] = rt;
+        slot[8 + (threadIdx.x >> 6)] = wfeat | wcost;
+    }
+#endif
     // ---- leave this tile's work estimate for rtx_order_tiles: the sum over the four waves, stored by the last one
     // to get here (LDS atomics of one wave execute in order, so the fourth increment sees all four sums)
     // (lane number from mbcnt: keeping tid & 63 alive across the whole kernel for this one test costs a register)
     if (a.tile_cost != nullptr && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
         atomicAdd(&s_cost[0], (uint32_t)__builtin_amdgcn_readfirstlane(wcost));
         if (atomicAdd(&s_cost[1], 1u) == (uint32_t)(kThreads / 64 - 1)) {
+            // the estimate by tile; when the workgroup started and ended by dispatch position (rtx_balance_tiles sets
+            // the two against each other: the workgroups that shared a CU, and how long that CU took)
+            const uint32_t n_tiles = gridDim.x * gridDim.y, pos = blockIdx.y * gridDim.x + blockIdx.x;
             a.tile_cost[by * gridDim.x + bx] = *reinterpret_cast<volatile uint32_t*>(&s_cost[0]);
+            a.tile_cost[n_tiles + pos] = *reinterpret_cast<volatile uint32_t*>(&s_cost[2]);
+#ifndef RTX_NO_END_STAMP
+            a.tile_cost[2u * n_tiles + pos] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
         }
     }
 }
@@ -1226,6 +1260,248 @@ __global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t*
     }
 }
 
+// rtx_balance_tiles: the dispatch order for a tile grid whose workgroups are all resident at once (n <= slots per CU x
+// n_cu; one workgroup, like rtx_order_tiles).  Then the blocks b, b + n_cu, b + 2 n_cu, ... share a compute unit
+// (observed on every launch: profiles/r02_f_cu_balance.md; which physical CU varies, the groups do not), nothing is
+// refilled, and the launch ends when the slowest group does -- in 1080p frame order a third later than the average
+// one.  Two steps:
+//   feedback  The instruction-count estimate ranks tiles well but is off by +-14 % on a group's sum (dependent
+//             chains, the planes, divergence), while a group's duration repeats from launch to launch to 0.3 us.  So the
+//             trace workgroups also leave their start and end times by dispatch position, and every tile carries a
+//             correction factor: the tiles of a group that took longer than the mean group are scaled up, the others
+//             down (damped, clamped), launch after launch.  cost' = (estimate + set-up) x factor.
+//   dealing   The n - (rounds-1) n_cu lightest tiles are the last round (the hardware puts those blocks on groups
+//             0, 1, ...).  The other rounds go heaviest first, and within a round the k-th heaviest tile goes to the
+//             group with the k-th smallest sum so far.
+// Any permutation renders the same frame; every position receives exactly one tile whatever the inputs hold (ranks come
+// from counting, positions from ranks).
+#ifdef RTX_ABLATE
+__device__ unsigned long long g_bal_stamps[16];
+#define BSTAMP(i) do { if (threadIdx.x == 0) { g_bal_stamps[i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define BSTAMP(i) do { } while (0)
+#endif
+// The pass runs beside the next frame's trace launch (a stream of its own), so it is shaped to fit into a slot that
+// launch leaves free: 256 threads, the trace kernel's register budget, under 38 KB of LDS -- a CU holding six trace
+// workgroups has room for exactly that.  (As one 1024-thread workgroup it needed a CU to itself and the frame beside it
+// paid 20 us for the seven workgroups that CU could not take.)
+constexpr int kBalanceMaxTiles = 2048;
+constexpr int kBalanceThreads = 256;
+constexpr int kBalancePerThread = kBalanceMaxTiles / kBalanceThreads;
+constexpr int kBalanceBins = 1024;
+constexpr uint32_t kCostSetup = 1800u; // per workgroup: tables, planes, staging (4 waves x ~4.5 passes' worth of time)
+
+__global__ __launch_bounds__(kBalanceThreads, RTX_WAVES_PER_EU) void rtx_balance_tiles(const uint32_t* __restrict__ cost, uint32_t n, uint32_t gx,
+                                                                                       uint32_t G, const uint32_t* prev_order, float* factor,
+                                                                                       uint32_t have_factor, uint32_t have_times, uint32_t* order)
+{
+    // s_a: the estimates by tile, later the corrected costs by rank; s_b: the tile that ran at each position, later the
+    // tile by rank
+    __shared__ uint32_t s_a[kBalanceMaxTiles];
+    __shared__ uint16_t s_b[kBalanceMaxTiles];
+    __shared__ float s_f[kBalanceMaxTiles];        // factor by tile
+    __shared__ float s_c[kBalanceMaxTiles];        // corrected cost by tile; before that, per group: earliest start, latest end
+    int32_t* s_first = reinterpret_cast<int32_t*>(s_c);
+    int32_t* s_last = s_first + kOrderThreads;
+    static_assert(2 * kOrderThreads <= kBalanceMaxTiles, "the groups' times share s_c");
+    __shared__ uint32_t s_hist[kBalanceBins];
+    __shared__ float s_sum[kOrderThreads];         // per group: duration, then the sum dealt so far
+    __shared__ float s_red[kBalanceThreads / 64];
+    __shared__ uint32_t s_lo[kBalanceThreads / 64], s_hi[kBalanceThreads / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    constexpr int kWaves = kBalanceThreads / 64;
+
+    BSTAMP(0);
+    for (uint32_t g = tid; g < (uint32_t)kOrderThreads; g += kBalanceThreads) {
+        s_first[g] = 0x7fffffff;
+        s_last[g] = (int32_t)0x80000000;
+        s_hist[g] = 0u;
+    }
+    const uint32_t ref = have_times ? cost[n] : 0u;
+    __syncthreads();
+    // ---- everything this needs from memory, requested before anything is used (clamped indices instead of branches:
+    // one round trip instead of eight); then the groups' first start and last end (a group's clocks are one XCD's:
+    // only differences within a group are used)
+    uint32_t c_in[kBalancePerThread], t0[kBalancePerThread], t1[kBalancePerThread], pk[kBalancePerThread];
+    float f_in[kBalancePerThread];
+#pragma unroll
+    for (int q = 0; q < kBalancePerThread; q++) {
+        const uint32_t i = tid + (uint32_t)q * kBalanceThreads;
+        const uint32_t ii = i < n ? i : n - 1u;
+        c_in[q] = cost[ii];
+        t0[q] = have_times ? cost[n + ii] : 0u;
+        t1[q] = have_times ? cost[2u * n + ii] : 0u;
+        pk[q] = prev_order != nullptr ? prev_order[ii] : 0u;
+        f_in[q] = have_factor ? factor[ii] : 1.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kBalancePerThread; q++) {
+        const uint32_t i = tid + (uint32_t)q * kBalanceThreads;
+        if (i < n) {
+            const uint32_t po = prev_order != nullptr ? (pk[q] >> 16) * gx + (pk[q] & 0xffffu) : i;
+            s_a[i] = c_in[q];
+            s_b[i] = (uint16_t)(po < n ? po : i);
+            s_f[i] = (f_in[q] >= 0.5f && f_in[q] <= 2.0f) ? f_in[q] : 1.0f;
+            if (have_times) {
+                atomicMin(&s_first[i % G], (int32_t)(t0[q] - ref));
+                atomicMax(&s_last[i % G], (int32_t)(t1[q] - ref));
+            }
+        }
+    }
+    __syncthreads();
+    BSTAMP(1);
+    // ---- feedback: how long each group took, against the mean
+    float tot = 0.0f;
+    for (uint32_t g = tid; g < G; g += kBalanceThreads) {
+        float dur = 0.0f;
+        if (have_times) {
+            dur = (float)(s_last[g] - s_first[g]);
+            dur = (dur > 0.0f && dur < 1.0e8f) ? dur : 0.0f; // (a second: nonsense)
+        }
+        s_sum[g] = dur;
+        tot += dur;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    if (lane == 0u) s_red[wave] = tot;
+    __syncthreads();
+    tot = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kWaves; k++) tot += s_red[k];
+    const float mean = tot / (float)G;
+    if (have_times && mean > 0.0f) {
+        for (uint32_t p = tid; p < n; p += kBalanceThreads) { // a dispatch position; s_b: the tile that ran there
+            const float d = s_sum[p % G];
+            if (d > 0.0f) {
+                float r = 1.0f + 0.7f * (d / mean - 1.0f);      // damped
+                r = r < 0.85f ? 0.85f : (r > 1.18f ? 1.18f : r);
+                const uint32_t t = s_b[p];                      // (a permutation: every tile once)
+                const float f = s_f[t] * r;
+                s_f[t] = f < 0.5f ? 0.5f : (f > 2.0f ? 2.0f : f);
+            }
+        }
+    }
+    __syncthreads();
+    BSTAMP(2);
+    // ---- corrected costs; ranks by a counting sort over 1024 classes, heaviest first
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    float total = 0.0f;
+    for (uint32_t i = tid; i < n; i += kBalanceThreads) {
+        const float f = s_f[i];
+        factor[i] = f;
+        const uint32_t c_in = s_a[i];
+        const float c = (float)(c_in < (1u << 24) ? c_in + kCostSetup : (1u << 24)) * f;
+        s_c[i] = c;
+        total += c;
+        const uint32_t u = (uint32_t)c;
+        lo = u < lo ? u : lo;
+        hi = u > hi ? u : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, d), h2 = __shfl_xor(hi, d);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+        total += __shfl_xor(total, d);
+    }
+    if (lane == 0u) {
+        s_lo[wave] = lo;
+        s_hi[wave] = hi;
+        s_red[wave] = total;
+    }
+    __syncthreads();
+    total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kWaves; k++) {
+        lo = s_lo[k] < lo ? s_lo[k] : lo;
+        hi = s_hi[k] > hi ? s_hi[k] : hi;
+        total += s_red[k];
+    }
+    const float to_bin = (float)kBalanceBins / ((float)(hi - lo) + 1.0f);
+    auto bin_of = [&](float c) { // 0 = heaviest
+        const uint32_t b = (uint32_t)((float)(hi - (uint32_t)c) * to_bin);
+        return b < (uint32_t)kBalanceBins ? b : (uint32_t)kBalanceBins - 1u;
+    };
+    // exclusive prefix sums over the 1024 classes in s_hist: four consecutive classes per thread, wave scan, wave totals
+    auto scan_hist = [&]() {
+        const uint32_t h0 = s_hist[4u * tid], h1 = s_hist[4u * tid + 1u], h2 = s_hist[4u * tid + 2u], h3 = s_hist[4u * tid + 3u];
+        const uint32_t mine = h0 + h1 + h2 + h3;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= (uint32_t)d) incl += o;
+        }
+        if (lane == 63u) s_lo[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine;
+#pragma unroll
+        for (int k = 0; k < kWaves; k++) {
+            before += (uint32_t)k < wave ? s_lo[k] : 0u;
+        }
+        s_hist[4u * tid] = before;
+        s_hist[4u * tid + 1u] = before + h0;
+        s_hist[4u * tid + 2u] = before + h0 + h1;
+        s_hist[4u * tid + 3u] = before + h0 + h1 + h2;
+        __syncthreads();
+    };
+    for (uint32_t i = tid; i < n; i += kBalanceThreads) {
+        atomicAdd(&s_hist[bin_of(s_c[i])], 1u);
+    }
+    __syncthreads();
+    scan_hist();
+    BSTAMP(3);
+    for (uint32_t i = tid; i < n; i += kBalanceThreads) {
+        const float c = s_c[i];
+        const uint32_t rank = atomicAdd(&s_hist[bin_of(c)], 1u);
+        s_a[rank] = __float_as_uint(c); // (the estimates are not needed any more, nor the positions)
+        s_b[rank] = (uint16_t)i;
+    }
+    __syncthreads();
+    BSTAMP(4);
+    // ---- dealing
+    auto put = [&](uint32_t pos, uint32_t rank) {
+        const uint32_t t = s_b[rank];
+        const uint32_t ty = t / gx, tx = t - ty * gx;
+        order[pos] = tx | (ty << 16);
+    };
+    const uint32_t rounds = (n + G - 1u) / G, tail0 = (rounds - 1u) * G;
+    for (uint32_t g = tid; g < G; g += kBalanceThreads) {
+        float sum0 = 0.0f;
+        if (tail0 + g < n) {
+            sum0 = __uint_as_float(s_a[tail0 + g]);
+            put(tail0 + g, tail0 + g);
+        }
+        s_sum[g] = sum0;
+    }
+    // Per round: rank the groups by their sums with the same counting sort (1024 classes over [0, 1.25 x the mean final
+    // sum]: a class is 0.12 % of a group's work wide, far below what the estimates are good for; ties take the order the
+    // atomics give), then the group with the k-th smallest sum takes the k-th heaviest tile of the round.
+    const float sum_to_bin = total > 0.0f ? (float)kBalanceBins * (float)G / (1.25f * total) : 0.0f;
+    auto sum_bin = [&](float v) {
+        const uint32_t b = (uint32_t)(v * sum_to_bin);
+        return b < (uint32_t)kBalanceBins ? b : (uint32_t)kBalanceBins - 1u;
+    };
+    BSTAMP(5);
+    for (uint32_t r = 0; r + 1u < rounds; r++) {
+        for (uint32_t k = tid; k < (uint32_t)kBalanceBins; k += kBalanceThreads) s_hist[k] = 0u;
+        __syncthreads();
+        for (uint32_t g = tid; g < G; g += kBalanceThreads) {
+            atomicAdd(&s_hist[sum_bin(s_sum[g])], 1u);
+        }
+        __syncthreads();
+        scan_hist();
+        for (uint32_t g = tid; g < G; g += kBalanceThreads) {
+            const float v = s_sum[g];
+            const uint32_t k = atomicAdd(&s_hist[sum_bin(v)], 1u); // < G: the classes hold G groups in all
+            put(r * G + g, r * G + k);
+            s_sum[g] = v + __uint_as_float(s_a[r * G + k]);
+        }
+        __syncthreads();
+    }
+    BSTAMP(6);
+}
+
 // rtx_expand: compact pixel words -> records, for up to kMaxExpandSeg segments (a segment = a run of pixels that
 // is contiguous in both buffers: one rank's rows of one frame).  Pure streaming: 4 bytes read, S written per pixel.
 // A workgroup takes kExpandPixels consecutive pixels of one segment, 256 at a time; each wave transposes the
@@ -1401,6 +1677,28 @@ extern "C" int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_ti
     }
     if (first_round > n_tiles) first_round = n_tiles;
     hipLaunchKernelGGL(rtx::rtx_order_tiles, dim3(1), dim3(rtx::kOrderThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, first_round, tile_order);
+    return (int)hipGetLastError();
+}
+
+extern "C" int rtx_k_launch_balance_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, const uint32_t* prev_order,
+                                          float* factor, int have_factor, int have_times, uint32_t* tile_order, void* stream_v)
+{
+    if (n_tiles == 0 || n_tiles > (uint32_t)rtx::kBalanceMaxTiles || gx == 0 || n_cu == 0 || n_cu > (uint32_t)rtx::kOrderThreads) {
+        return (int)hipErrorInvalidValue;
+    }
+#ifdef RTX_ABLATE
+    if (getenv("RTX_BAL_DEBUG")) {
+        static int calls = 0;
+        if (++calls == 12) {
+            unsigned long long h[16];
+            hipDeviceSynchronize();
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(rtx::g_bal_stamps), sizeof h);
+            for (int i = 1; i < 7; i++) fprintf(stderr, "balance phase %d: %llu clocks\n", i, h[i] - h[i - 1]);
+        }
+    }
+#endif
+    hipLaunchKernelGGL(rtx::rtx_balance_tiles, dim3(1), dim3(rtx::kBalanceThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, prev_order,
+                       factor, (uint32_t)have_factor, (uint32_t)have_times, tile_order);
     return (int)hipGetLastError();
 }
 

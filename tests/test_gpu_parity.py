@@ -513,9 +513,9 @@ def _render_into_poisoned_buffer(R, ctx, p, mode, buf):
 @pytest.mark.parametrize("period", [-1, 1, 3])
 def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     """The order the workgroups take the macro tiles in is derived from the previous frames' work estimates; any
-    permutation must give the same bytes.  C2 over several frames (order refreshed after every frame / every third /
-    the library's default: five sub-tiles per workgroup so the grid is one dispatch round, refreshed after frames 1, 2
-    and 16), every frame against the golden hash."""
+    permutation must give the same bytes.  C2 over many frames (order refreshed with period 1 / 3 / the library's
+    default: five sub-tiles per workgroup so the grid is one dispatch round, balanced by rtx_balance_tiles on a stream
+    of its own), the first frames against the golden hash, the rest against the first on the device."""
     import torch
     p, sph, pl = R.config_inputs("C2")
     ctx.set_scene(sph, pl)
@@ -524,8 +524,29 @@ def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
     assert ctx.get_option(R.OPT_TILE_ORDER) == -1   # the default: auto
     set_kernel(R, ctx, "auto" if period < 0 else "binned", tile_order=period)
-    for i in range(18 if period < 0 else 7):
-        assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold, "frame %d" % i
+    first = None
+    for i in range(150 if period < 0 else 40):
+        # (auto: the balancing passes run on their own stream, every fourth frame at first and every 64th from frame 64
+        # on; each switches the launches to the other half of the order buffer three frames later)
+        if i < 7:
+            got = _render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)
+            assert O.fnv1a64(got) == gold, "frame %d" % i
+            if first is None:
+                first = torch.from_numpy(got).cuda()
+        else:
+            buf.fill_(0xEE)
+            torch.cuda.synchronize()
+            ctx.render_rows(p, R.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0)
+            ctx.synchronize()
+            assert torch.equal(buf, first), "frame %d" % i
+    # and queued back to back, as a renderer submits them (passes, waits and switches with launches in flight)
+    bufs = [torch.full_like(buf, 0xEE) for _ in range(3)]
+    torch.cuda.synchronize()
+    for i in range(100):
+        ctx.render_rows(p, R.RGB_ASCII, 0, H, d_out=bufs[i % 3].data_ptr(), out_row_base=0)
+    ctx.synchronize()
+    for b in bufs:
+        assert torch.equal(b, first)
     set_kernel(R, ctx, "binned", tile_order=0)
     assert O.fnv1a64(_render_into_poisoned_buffer(R, ctx, p, R.RGB_ASCII, buf)) == gold
     set_kernel(R, ctx, "auto", tile_order=-1)

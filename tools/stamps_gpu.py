@@ -40,7 +40,7 @@ np.save(os.path.join(ROOT, "gpurun_out", "stamps_sub%d%s_order%d.npy" % (sub, "_
 s = s[s[:, 15] != 0]
 n = s.shape[0]
 if light:
-    s[:, 0:13] = 0
+    s[:, 0:3] = 0   # (the raw dump keeps the per-wave SIMD / end time / work estimate of slots 0-11)
 t0 = s[:, 0].min()
 rt0 = s[:, 15].min()
 npass = sub

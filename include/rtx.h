@@ -92,7 +92,8 @@ enum rtx_option {
                                * tiles that share 128-byte lines; 0 = frame order; k > 0 = on for every grid, order derived after
                                * the first two frames of a grid and then after every k-th (auto: 16) */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
-                               * (needs at most 4 sub-tiles per workgroup; otherwise it stays off) */
+                               * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
+                               * stays off) */
 };
 
 /* Flags of rtx_render_rows. */

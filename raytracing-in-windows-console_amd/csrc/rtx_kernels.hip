@@ -49,6 +49,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 constexpr int kThreads = 256;
 constexpr int kListCapBrute = 1024;  // candidate records per flush (brute: every sphere is a candidate)
 constexpr int kListCapCull = 704;    // culling kernels: room for one more 512-sphere step while <= 192 are listed; 8 workgroups per CU
+constexpr int kListCapRefine = 640;  // REFINE: ... while <= 128 are listed
 constexpr float kNoHit = 99999999.f; // RayTracing.h:21
 
 // RayTracing.h:97-115 (68 glyphs).
@@ -359,7 +360,9 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
 {
     float s;
     const bool rejected = sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s);
-    slow += __ballot(!rejected) != 0ull ? 1u : 0u; // candidates some lane of this wave takes to the exact test
+#ifdef RTX_ABLATE
+    bool updated = false;
+#endif
     if (!rejected) {
         ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
         float t;
@@ -368,13 +371,17 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
             if (t < best.t || (t == best.t && ki < best.k)) {
                 best.t = t;
                 best.k = ki;
+#ifdef RTX_ABLATE
+                updated = true;
+#endif
             }
         }
     }
+#ifdef RTX_ABLATE
+    // diagnostic: candidates some lane of this wave takes to the exact test; of those, how many change no lane's best hit
+    slow += (__ballot(!rejected) != 0ull ? 1u : 0u) + ((__ballot(!rejected) != 0ull && __ballot(updated) == 0ull) ? 0x10000u : 0u);
+#endif
 }
-
-// (Requesting the next record one test ahead -- one or two records in flight -- was measured and dropped: 1-2 %
-// slower; with 6 waves per SIMD the LDS latency of the broadcast read is already hidden.)
 __device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best, uint32_t& slow)
 {
     for (uint32_t i = 0; i < total; i++) {
@@ -407,6 +414,7 @@ __device__ __forceinline__ Ray ray_from_tables(const Camera& c, float4 A, float4
 constexpr uint32_t kCostPass = 100u, kCostCandidate = 3u, kCostShaded = 330u;
 
 constexpr int kMaxMacro = 128;    // macro tile is at most 128 x 128 pixels
+constexpr int kMaxMacroRefine = 64; // ... 64 x 64 for the REFINE kernels
 constexpr int kChunk = 2 * kThreads; // spheres staged per barrier: two per thread
 constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes take the direct path
 
@@ -512,7 +520,7 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
 }
 
 constexpr int kRefineSub = 4;      // REFINE: at most this many sub-tiles (lanes 5 .. 5 + 20 per sub-tile build the pyramids)
-constexpr int kWaveListCap = 192;  // REFINE: candidates a wave keeps for its own 64 pixels; more -> it scans the whole list
+constexpr int kWaveListCap = 128;  // REFINE: candidates a wave keeps for its own 64 pixels; more -> it scans the whole list
 
 // REFINE (dense scenes, long candidate lists): before a wave scans the workgroup's list for its 64 pixels it
 // tests the list, one entry per lane, against the pyramid of just those pixels -- same conservative test and
@@ -523,11 +531,14 @@ template <int MODE, bool CULL, int OUT, bool REFINE>
 #endif
 __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KArgs a)
 {
-    constexpr int kListCap = CULL ? kListCapCull : kListCapBrute;
+    // REFINE (dense scenes, short per-cell lists, at most 4 sub-tiles): a shorter list and smaller tables, so that its
+    // extra arrays still leave room for 7 workgroups per CU (under 23 405 bytes each)
+    constexpr int kListCap = CULL ? (REFINE ? kListCapRefine : kListCapCull) : kListCapBrute;
+    constexpr int kTable = REFINE ? kMaxMacroRefine : kMaxMacro;
     __shared__ float4 s_rec[kListCap];
     __shared__ uint32_t s_idx[kListCap];
-    __shared__ float4 s_col[kMaxMacro];          // per column: (m0, m4, m8) * vx
-    __shared__ float4 s_row[kMaxMacro];          // per row:    (m1, m5, m9) * vy
+    __shared__ float4 s_col[kTable];             // per column: (m0, m4, m8) * vx
+    __shared__ float4 s_row[kTable];             // per row:    (m1, m5, m9) * vy
     __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
     __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
     __shared__ __attribute__((aligned(4))) uint8_t s_ramp[68]; // the glyph ramp (RayTracing.h:97-115)
@@ -932,8 +943,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         wcost += kCostPass + kCostCandidate * scanned + (__ballot(in_frame && distance <= cam.far) != 0ull ? kCostShaded : 0u);
         STAMP(3 + (j < 9u ? j : 9u));
 #ifdef RTX_ABLATE
-        wfeat += ((unsigned long long)slow << 20) | ((__ballot(in_frame && distance <= cam.far) != 0ull ? 1ull : 0ull) << 32) | (1ull << 36) |
-                 ((unsigned long long)scanned << 40) | ((__ballot(plane_q != 0xffffffffu) != 0ull ? 1ull : 0ull) << 52);
+        wfeat += ((unsigned long long)(slow & 0xffffu) << 20) | ((__ballot(in_frame && distance <= cam.far) != 0ull ? 1ull : 0ull) << 32) | (1ull << 36) |
+                 ((unsigned long long)scanned << 40) | ((unsigned long long)(slow >> 16) << 52);
         if (a.stamps && threadIdx.x == 0) {
             unsigned long long rt;
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
@@ -1603,6 +1614,9 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     *hip_error = 0;
     if (a->nsub == 0 || nx * ny != a->nsub || mw > (uint32_t)kMaxMacro || mh > (uint32_t)kMaxMacro || mw + mh > (uint32_t)kThreads) {
         return nullptr;
+    }
+    if (cull && a->refine && (mw > (uint32_t)kMaxMacroRefine || mh > (uint32_t)kMaxMacroRefine)) {
+        return nullptr; // (rtx_render_rows does not ask for this)
     }
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);

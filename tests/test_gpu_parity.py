@@ -320,8 +320,11 @@ def test_random_scenes_and_cameras_binned_vs_brute_vs_oracle(R, ctx, seed):
                         got = ctx.render_to_host(p, R.RGB_ASCII)
                         assert_same(got, want, O.RGB_ASCII, w, "random scene %d %s tile %d sub %d two-level %d refine %d"
                                     % (seed, kernel, tile, sub, two, refine))
-                        if refine:
+                        # (REFINE is declined for macro tiles beyond 64 x 64 pixels -- its tables are that large)
+                        if refine and tile in (0, 4) and sub <= 2:
                             assert ctx.last_kernel.endswith(",refine>")
+                        if not refine:
+                            assert not ctx.last_kernel.endswith(",refine>")
 
 
 def test_per_pixel_values_within_tolerance(R, ctx):
@@ -468,7 +471,10 @@ def test_per_wave_refinement_gives_the_same_frame(R, ctx, mode, sub, tile):
     for refine in (0, 1):
         set_kernel(R, ctx, "binned", tile, sub, 0, refine)
         frames.append(ctx.render_to_host(p, mode))
-        assert ctx.last_kernel.endswith(",refine>") == bool(refine)
+        if tile == 6:   # 64-pixel-wide sub-tiles: two of them side by side are beyond the REFINE kernels' 64 x 64 tables
+            assert not ctx.last_kernel.endswith(",refine>") or bool(refine)
+        else:
+            assert ctx.last_kernel.endswith(",refine>") == bool(refine)
     set_kernel(R, ctx, "auto")
     assert np.array_equal(frames[0], frames[1])
     g = U.load_golden().get("C2_%s" % O.MODE_NAMES[mode])

@@ -301,7 +301,9 @@ def main():
             kernel_ms = elapsed / K * 1e3
         else:
             Kr = max(10, min(K, 100))
-            for _ in range(5):
+            # (the context's own stream has its own dispatch order: let it settle as the render streams' did --
+            # the library balances a tile grid over its first launches on a stream, and keeps refining every 64th)
+            for _ in range(5 if F == 1 else 1000):
                 ctx.render(params, mode)
             ctx.synchronize()
             singles = []

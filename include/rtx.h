@@ -85,12 +85,14 @@ enum rtx_option {
                                * scratch is O(spheres)).  A cell whose list does not fit falls back to the whole scene: slower,
                                * the same frame */
     RTX_OPT_TILE_ORDER = 6,   /* binned kernel: dispatch the macro tiles heaviest first and dealt evenly over the CUs, from the work
-                               * estimates the previous frames of the same tile grid left behind (speed only: the frame is the same
-                               * in any order).  -1 = auto (default): on for tile grids whose workgroups are all resident at once
-                               * (then 5 or 6 sub-tiles per workgroup are chosen to make that so, e.g. at 1080p: one launch alone
-                               * 29.3 -> 28.1 us), off for larger grids, where it gains nothing and at 8K costs 10 % by separating
-                               * tiles that share 128-byte lines; 0 = frame order; k > 0 = on for every grid, order derived after
-                               * the first two frames of a grid and then after every k-th (auto: 16) */
+                               * estimates (and, for grids of one dispatch round, the measured durations) that earlier frames of
+                               * the same tile grid on the same stream left behind.  Speed only: the frame is the same in any
+                               * order.  -1 = auto (default): on for tile grids whose workgroups are all resident at once (5 or 6
+                               * sub-tiles per workgroup are chosen to make that so, e.g. at 1080p); those are balanced by
+                               * rtx_balance_tiles on a stream of the library's own, every 4th frame for the first 64 frames of a
+                               * grid, then every 64th (one 1080p launch alone: 29.3 -> 25.9 us).  Off for larger grids, where
+                               * ordering gains nothing and at 8K costs 10 % by separating tiles that share 128-byte lines.
+                               * 0 = frame order; k > 0 = on for every grid, the order re-derived every k-th frame */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
                                * stays off) */

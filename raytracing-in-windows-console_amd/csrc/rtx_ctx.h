@@ -69,7 +69,6 @@ struct rtx_ctx {
         bool have_factor = false;
         int cur = 0;
         int pending = 0;             // 0 = none; 1 = a balancing pass was queued after the last launch; 2 = ... before the last launch
-        hipStream_t aux = nullptr;   // the balancing passes' stream
         hipEvent_t ev_rec = nullptr, ev_done = nullptr;
         size_t cap = 0;              // tiles the buffers hold
         uint64_t key[3] = {0, 0, 0};
@@ -77,6 +76,7 @@ struct rtx_ctx {
         uint64_t frames = 0;         // traces of this grid since the last reset
     };
     std::vector<TileOrder> tile_orders;
+    hipStream_t aux_stream = nullptr; // the balancing passes' stream (created with the first pass)
     int64_t opt_tile_order = -1;    // -1 = auto (grids of one dispatch round, period 16), 0 = off, k = on: re-derive the order after
                                     // the 1st and 2nd frame of a grid, then every k-th
     int n_cu = 0;                   // compute units of the device

@@ -356,6 +356,9 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
 }
 
 // Exact tests of one ray against the candidate list (index is wave-uniform: LDS broadcast reads).
+// HOISTED: ray.divTwoA was computed before the loop (dense scenes: several candidates per pass reach the exact test, so
+// once per ray is cheaper than once per exact test; sparse scenes: 1 in 3 passes reaches none)
+template <bool HOISTED>
 __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, uint32_t i, Best& best, uint32_t& slow)
 {
     float s;
@@ -364,7 +367,7 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
     bool updated = false;
 #endif
     if (!rejected) {
-        ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
+        if (!HOISTED) ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
         float t;
         if (sphere_hit(ray, s, sr.w, t)) {
             const uint32_t ki = s_idx[i];
@@ -382,10 +385,11 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
     slow += (__ballot(!rejected) != 0ull ? 1u : 0u) + ((__ballot(!rejected) != 0ull && __ballot(updated) == 0ull) ? 0x10000u : 0u);
 #endif
 }
+template <bool HOISTED>
 __device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best, uint32_t& slow)
 {
     for (uint32_t i = 0; i < total; i++) {
-        test_candidate(ray, s_rec[i], s_idx, i, best, slow);
+        test_candidate<HOISTED>(ray, s_rec[i], s_idx, i, best, slow);
     }
 }
 
@@ -763,6 +767,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         const bool newline_col = col + 1u == a.W;
         // lanes outside the frame trace a clamped pixel (the tables clamp) so every lane runs the same loops
         Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
+        if (REFINE) ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93, once per ray here (see test_candidate)
         Best b;
         b.t = kNoHit;
         b.k = 0xffffffffu;
@@ -805,12 +810,12 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
                     for (uint32_t q = 0; q < cnt; q++) {
                         const uint32_t i = s_wlist[wave][q];
-                        test_candidate(ray, s_rec[i], s_idx, i, b, slow);
+                        test_candidate<REFINE>(ray, s_rec[i], s_idx, i, b, slow);
                     }
                 }
             }
             if (!refined) {
-                if (!ABL(4u)) scan_candidates(ray, s_rec, s_idx, total, b, slow);
+                if (!ABL(4u)) scan_candidates<REFINE>(ray, s_rec, s_idx, total, b, slow);
             }
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
@@ -842,7 +847,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
                     lds_barrier();
-                    scan_candidates(ray, s_rec, s_idx, tot, b, slow);
+                    scan_candidates<REFINE>(ray, s_rec, s_idx, tot, b, slow);
                     tot = 0;
                 }
             }

@@ -558,6 +558,27 @@ def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     set_kernel(R, ctx, "auto", tile_order=-1)
 
 
+def test_contexts_end_with_a_balancing_pass_in_flight(R):
+    """rtx_destroy right after launches whose balancing pass (own stream) is still queued, and option changes between
+    such launches: nothing may be freed under a running pass, and every frame stays the frame."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+    for n_frames in (1, 2, 3, 5):
+        c = R.Context(1920, 1080)
+        c.set_scene(sph, pl)
+        for i in range(n_frames):
+            c.render(p, R.RGB_ASCII)
+            if i == 1:
+                c.set_option(R.OPT_TILE_ORDER, 0)
+                c.render(p, R.RGB_ASCII)
+                c.set_option(R.OPT_TILE_ORDER, -1)
+        if n_frames == 5:
+            assert O.fnv1a64(c.read_frame(20 * 1920 * 1080)) == gold
+        c.close()   # no synchronize before it
+    torch.cuda.synchronize()
+
+
 def test_tile_order_with_a_moving_camera_changing_grids_and_slabs(R, ctx):
     """Stale estimates (the camera moves every frame), a different tile grid every few frames (frame size, sub-tile
     count, two-level culling on and off) and row slabs: always the frame the brute kernel renders in frame order."""

@@ -558,6 +558,17 @@ def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     set_kernel(R, ctx, "auto", tile_order=-1)
 
 
+def test_tile_order_option_values(R, ctx):
+    for ok in (-1, 0, 1, 64, 1 << 20):
+        ctx.set_option(R.OPT_TILE_ORDER, ok)
+        assert ctx.get_option(R.OPT_TILE_ORDER) == ok
+    for bad in (-2, -100, (1 << 20) + 1):
+        with pytest.raises(R.RtxError) as e:
+            ctx.set_option(R.OPT_TILE_ORDER, bad)
+        assert e.value.status == R.ERR_INVALID_ARGUMENT
+    ctx.set_option(R.OPT_TILE_ORDER, -1)
+
+
 def test_contexts_end_with_a_balancing_pass_in_flight(R):
     """rtx_destroy right after launches whose balancing pass (own stream) is still queued, and option changes between
     such launches: nothing may be freed under a running pass, and every frame stays the frame."""

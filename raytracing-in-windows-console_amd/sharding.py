@@ -121,10 +121,19 @@ class RowShardedFrames:
         return self.frames[self.where[i]]
 
 
-def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize, prewarm=0):
+def _median(xs):
+    ys = sorted(xs)
+    n = len(ys)
+    return ys[n // 2] if n % 2 else 0.5 * (ys[n // 2 - 1] + ys[n // 2])
+
+
+def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize, prewarm=0, min_total=0.0, max_repeats=1):
     """bench.py's timing contract for N > 1: warm-up, then exactly `steps` frames between barrier +
     synchronize on both sides; returns the MAX over ranks of the elapsed seconds.  `prewarm` more frames run
-    first, neither timed nor counted (clock ramp of an idle GPU; a fixed count so that all ranks agree)."""
+    first, neither timed nor counted (clock ramp of an idle GPU; a fixed count so that all ranks agree).
+    With max_repeats > 1 the window of `steps` frames is repeated, each time from a drained pipeline and between
+    barriers, until `min_total` seconds have been measured (the decision uses the all-reduced times, so every rank
+    takes it alike); the MEDIAN window is returned and all of them are left in pipe.timed_windows."""
     import time
     # communicator set-up (not a timed or counted step): one full rotation of roots, so that every pair of
     # ranks that will exchange slabs has done so once
@@ -134,18 +143,24 @@ def timed_frames(dist, torch, pipe, render, steps, warmup, device, synchronize, 
     for i in range(warmup):
         pipe.step(i, render)
     pipe.drain()
-    dist.barrier()
-    synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        pipe.step(i, render)
-    pipe.drain()
-    synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    windows = []
+    while True:
+        dist.barrier()
+        synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            pipe.step(i, render)
+        pipe.drain()
+        synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        windows.append(float(t.item()))
+        if len(windows) >= max_repeats or sum(windows) >= min_total:
+            break
+    pipe.timed_windows = windows
+    return _median(windows)
 
 
 class RowShardedRounds:
@@ -313,26 +328,33 @@ class RowShardedRounds:
         return self.frames[b][m]
 
 
-def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize, prewarm=0):
+def timed_rounds(dist, torch, pipe, render_round, steps, warmup, device, synchronize, prewarm=0, min_total=0.0, max_repeats=1):
     """bench.py's timing contract for RowShardedRounds: warm-up, then exactly `steps` frames between
     barrier + synchronize on both sides; returns (MAX over ranks of the elapsed seconds, first timed round).
     `prewarm` more frames run first, neither timed nor counted (clock ramp of an idle GPU; a fixed count so that
-    all ranks agree)."""
+    all ranks agree).  With max_repeats > 1 the window of `steps` frames is repeated as in timed_frames: the MEDIAN
+    window and the first round of the LAST window are returned, all windows are left in pipe.timed_windows."""
     import time
     # communicator set-up: one full round, neither timed nor counted; then the run-in
     q = pipe.run(0, pipe.round_frames + prewarm, render_round)
     pipe.drain()
     q = pipe.run(q, warmup, render_round)
     pipe.drain()
-    dist.barrier()
-    synchronize()
-    t0 = time.perf_counter()
-    q0 = q
-    pipe.run(q, steps, render_round)
-    pipe.drain()
-    synchronize()
-    dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item()), q0
+    windows = []
+    while True:
+        dist.barrier()
+        synchronize()
+        t0 = time.perf_counter()
+        q0 = q
+        q = pipe.run(q, steps, render_round)
+        pipe.drain()
+        synchronize()
+        dist.barrier()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        windows.append(float(t.item()))
+        if len(windows) >= max_repeats or sum(windows) >= min_total:
+            break
+    pipe.timed_windows = windows
+    return _median(windows), q0

@@ -1,0 +1,12 @@
+export RTX_BENCH_FORCE_DIST=1
+run() { printf "%-60s " "$*"
+  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
+    bench.py --gpus 1 --no-cpu-baseline "$@" 2>gpurun_out/force_dist.err | tail -1 | python3 tools/fmt_bench_line.py || tail -3 gpurun_out/force_dist.err; }
+run --steps 20 --warmup 5
+run --steps 20 --warmup 5 --frames-per-root 4
+run --steps 20 --warmup 5 --frames-per-root 2
+run --steps 20 --warmup 5 --frames-per-root 1
+run --steps 20 --warmup 5 --exchange p2p
+run --steps 20 --warmup 5 --graphs 0
+run --steps 200 --warmup 5
+run --steps 2000 --warmup 100

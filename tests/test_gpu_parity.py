@@ -207,6 +207,36 @@ def test_row_slabs_assemble_to_the_full_frame(R, ctx):
         assert np.array_equal(np.concatenate(pieces), full), "slabs parts=%d" % parts
 
 
+def test_c2_row_slabs_with_the_librarys_own_choices(R, ctx):
+    """Config 2 as the row slabs of 2 / 3 / 4 / 8 ranks with every option on auto: the sub-tile count follows the
+    slab's size (3 / 2 / 2 / 1), slabs from half a megapixel up are balanced (orders switched while the frames
+    repeat).  Each slab is rendered 1, 5 and 9 times in a row; the assembled frame is the golden one every time."""
+    import torch
+    set_kernel(R, ctx, "auto", tile_order=-1)
+    p, sph, pl = R.config_inputs("C2")
+    ctx.set_scene(sph, pl)
+    W, H = int(p.x), int(p.y)
+    gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+    dst = torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda")
+    first = None
+    for parts in (2, 3, 4, 8):
+        bounds = [H * i // parts for i in range(parts + 1)]
+        for rep in range(3):
+            dst.fill_(0xEE)
+            torch.cuda.synchronize()
+            for i in range(parts):
+                # the same slab several times in a row, as a rank renders it frame after frame (a stream keeps one
+                # dispatch order, for the grid it saw last)
+                for _ in range(1 + 4 * rep):
+                    ctx.render_rows(p, R.RGB_ASCII, bounds[i], bounds[i + 1] - bounds[i], d_out=dst.data_ptr(), out_row_base=0)
+            ctx.synchronize()
+            if first is None:
+                assert O.fnv1a64(dst.cpu().numpy()) == gold
+                first = dst.clone()
+            else:
+                assert torch.equal(dst, first), "parts=%d, repetition %d" % (parts, rep)
+
+
 def test_mode_switch_leaves_reference_zero_semantics(R, ctx):
     """RGB frame, then an 8-bit frame in the same buffer: bytes past 12*W*H must read as zero, as after
     the reference's per-frame memset (RayTracingManager.cu:86)."""

@@ -67,6 +67,8 @@ struct rtx_ctx {
         uint32_t* order = nullptr;   // two orders of `cap` tiles: the one in use (cur) and the one a balancing pass writes
         float* factor = nullptr;     // per-tile correction of the estimate (rtx_balance_tiles)
         bool have_factor = false;
+        float last_view[12] = {0}, order_view[12] = {0}, pending_view[12] = {0}; // rotation + position: of the last launch, of the
+                                     // launch the order in use was measured on, of the launch the pass in flight reads
         int cur = 0;
         int pending = 0;             // 0 = none; 1 = a balancing pass was queued after the last launch; 2 = ... before the last launch
         hipEvent_t ev_rec = nullptr, ev_done = nullptr;

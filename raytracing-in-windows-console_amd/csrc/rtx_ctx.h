@@ -69,6 +69,7 @@ struct rtx_ctx {
         bool have_factor = false;
         float last_view[12] = {0}, order_view[12] = {0}, pending_view[12] = {0}; // rotation + position: of the last launch, of the
                                      // launch the order in use was measured on, of the launch the pass in flight reads
+        double last_drift = 0.0, order_drift = 0.0, pending_drift = 0.0; // ctx->scene_drift at the same three launches
         int cur = 0;
         int pending = 0;             // 0 = none; 1 = a balancing pass was queued after the last launch; 2 = ... before the last launch
         hipEvent_t ev_rec = nullptr, ev_done = nullptr;
@@ -79,6 +80,9 @@ struct rtx_ctx {
     };
     std::vector<TileOrder> tile_orders;
     hipStream_t aux_stream = nullptr; // the balancing passes' stream (created with the first pass)
+    double scene_drift = 0.0;        // how far any sphere can have moved since the context was created (rtx_update_objects:
+                                     // |dt| x the largest speed; scene edits add 1e3): dispatch orders go stale with it
+    float max_speed = 0.0f;          // largest |speed| any sphere was given
     int64_t opt_tile_order = -1;    // -1 = auto (grids of one dispatch round, period 16), 0 = off, k = on: re-derive the order after
                                     // the 1st and 2nd frame of a grid, then every k-th
     int n_cu = 0;                   // compute units of the device

@@ -421,6 +421,7 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
     hipLaunchKernelGGL(rtx::rtx_update_spheres, dim3(blocks), dim3(rtx::kThreads), 0, ctx->stream,
                        (float4*)ctx->d_sph_geom.p, (float4*)ctx->d_sph_motion.p, ctx->ns, dt);
     RTX_HIP(ctx, hipGetLastError());
+    ctx->scene_drift += std::fabs(dt) * (double)ctx->max_speed; // (dispatch orders age with the scene: rtx_render_rows)
     return RTX_OK;
 }
 

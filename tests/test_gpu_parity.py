@@ -588,6 +588,34 @@ def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     set_kernel(R, ctx, "auto", tile_order=-1)
 
 
+def test_every_frame_of_four_streams_in_flight_is_the_frame(R):
+    """Four render streams, frames queued round-robin without waiting (the bench's default form), from a fresh context so
+    that the balancing passes and order switches of the first 64 launches per stream fall into the checked frames: every
+    one of 512 frames lands in its own buffer of a ring and is compared with the golden frame on the device."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    c = R.Context(W, H)
+    try:
+        c.set_scene(sph, pl)
+        c.render(p, R.RGB_ASCII)
+        want = torch.from_numpy(c.read_frame(20 * W * H)).cuda()
+        assert O.fnv1a64(want.cpu().numpy()) == U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        ring = [torch.empty(20 * W * H, dtype=torch.uint8, device="cuda") for _ in range(32)]
+        for rnd in range(16):
+            for b in ring:
+                b.fill_(0xEE)
+            torch.cuda.synchronize()
+            for i, b in enumerate(ring):
+                c.render_rows(p, R.RGB_ASCII, 0, H, d_out=b.data_ptr(), out_row_base=0, stream=streams[i % 4].cuda_stream)
+            torch.cuda.synchronize()
+            for i, b in enumerate(ring):
+                assert torch.equal(b, want), "round %d, frame %d" % (rnd, i)
+    finally:
+        c.close()
+
+
 def test_tile_order_option_values(R, ctx):
     for ok in (-1, 0, 1, 64, 1 << 20):
         ctx.set_option(R.OPT_TILE_ORDER, ok)

@@ -1309,7 +1309,8 @@ constexpr uint32_t kCostSetup = 1800u; // per workgroup: tables, planes, staging
 
 __global__ __launch_bounds__(kBalanceThreads, RTX_WAVES_PER_EU) void rtx_balance_tiles(const uint32_t* __restrict__ cost, uint32_t n, uint32_t gx,
                                                                                        uint32_t G, const uint32_t* prev_order, float* factor,
-                                                                                       uint32_t have_factor, uint32_t have_times, uint32_t* order)
+                                                                                       uint32_t have_factor, uint32_t have_times, uint32_t* order,
+                                                                                       float damping, float max_step)
 {
     // s_a: the estimates by tile, later the corrected costs by rank; s_b: the tile that ran at each position, later the
     // tile by rank
@@ -1389,8 +1390,8 @@ __global__ __launch_bounds__(kBalanceThreads, RTX_WAVES_PER_EU) void rtx_balance
         for (uint32_t p = tid; p < n; p += kBalanceThreads) { // a dispatch position; s_b: the tile that ran there
             const float d = s_sum[p % G];
             if (d > 0.0f) {
-                float r = 1.0f + 0.7f * (d / mean - 1.0f);      // damped
-                r = r < 0.85f ? 0.85f : (r > 1.18f ? 1.18f : r);
+                float r = 1.0f + damping * (d / mean - 1.0f);
+                r = r < 1.0f - max_step ? 1.0f - max_step : (r > 1.0f + max_step ? 1.0f + max_step : r);
                 const uint32_t t = s_b[p];                      // (a permutation: every tile once)
                 const float f = s_f[t] * r;
                 s_f[t] = f < 0.5f ? 0.5f : (f > 2.0f ? 2.0f : f);
@@ -1716,8 +1717,14 @@ extern "C" int rtx_k_launch_balance_tiles(const uint32_t* tile_cost, uint32_t n_
         }
     }
 #endif
+    // how much of a group's deviation from the mean duration goes into its tiles' factors per pass, and the largest step
+    float damping = 0.7f, max_step = 0.18f;
+#ifdef RTX_ABLATE
+    if (const char* e = getenv("RTX_BAL_DAMPING")) damping = (float)atof(e);
+    if (const char* e = getenv("RTX_BAL_MAX_STEP")) max_step = (float)atof(e);
+#endif
     hipLaunchKernelGGL(rtx::rtx_balance_tiles, dim3(1), dim3(rtx::kBalanceThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, prev_order,
-                       factor, (uint32_t)have_factor, (uint32_t)have_times, tile_order);
+                       factor, (uint32_t)have_factor, (uint32_t)have_times, tile_order, damping, max_step);
     return (int)hipGetLastError();
 }
 

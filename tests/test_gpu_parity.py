@@ -588,7 +588,8 @@ def test_tile_order_keeps_every_frame_identical(R, ctx, period):
     set_kernel(R, ctx, "auto", tile_order=-1)
 
 
-def test_every_frame_of_four_streams_in_flight_is_the_frame(R):
+@pytest.mark.parametrize("mode", [O.RGB_ASCII, O.BIT_ASCII, O.RGB_NORMALS])
+def test_every_frame_of_four_streams_in_flight_is_the_frame(R, mode):
     """Four render streams, frames queued round-robin without waiting (the bench's default form), from a fresh context so
     that the balancing passes and order switches of the first 64 launches per stream fall into the checked frames: every
     one of 512 frames lands in its own buffer of a ring and is compared with the golden frame on the device."""
@@ -598,17 +599,24 @@ def test_every_frame_of_four_streams_in_flight_is_the_frame(R):
     c = R.Context(W, H)
     try:
         c.set_scene(sph, pl)
-        c.render(p, R.RGB_ASCII)
-        want = torch.from_numpy(c.read_frame(20 * W * H)).cuda()
-        assert O.fnv1a64(want.cpu().numpy()) == U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+        S = 20 if mode >= O.RGB_ASCII else 12
+        c.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)      # the frame to compare with: brute kernel, frame order
+        c.render(p, mode)
+        want = torch.from_numpy(c.read_frame(20 * W * H)[:S * W * H]).cuda()
+        g = U.load_golden().get("C2_%s" % O.MODE_NAMES[mode])
+        if g:
+            full = np.zeros(20 * W * H, dtype=np.uint8)
+            full[:S * W * H] = want.cpu().numpy()
+            assert O.fnv1a64(full) == g["frame_fnv1a64"]
+        c.set_option(R.OPT_KERNEL, R.KERNEL_AUTO)
         streams = [torch.cuda.Stream() for _ in range(4)]
-        ring = [torch.empty(20 * W * H, dtype=torch.uint8, device="cuda") for _ in range(32)]
-        for rnd in range(16):
+        ring = [torch.empty(S * W * H, dtype=torch.uint8, device="cuda") for _ in range(32)]
+        for rnd in range(16 if mode == O.RGB_ASCII else 6):
             for b in ring:
                 b.fill_(0xEE)
             torch.cuda.synchronize()
             for i, b in enumerate(ring):
-                c.render_rows(p, R.RGB_ASCII, 0, H, d_out=b.data_ptr(), out_row_base=0, stream=streams[i % 4].cuda_stream)
+                c.render_rows(p, mode, 0, H, d_out=b.data_ptr(), out_row_base=0, stream=streams[i % 4].cuda_stream)
             torch.cuda.synchronize()
             for i, b in enumerate(ring):
                 assert torch.equal(b, want), "round %d, frame %d" % (rnd, i)

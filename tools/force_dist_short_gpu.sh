@@ -1,3 +1,4 @@
+# The world_size-1 walk of bench.py at the driver's K (tools/force_dist_gpu.sh for the long form)
 export RTX_BENCH_FORCE_DIST=1
 run() { printf "%-60s " "$*"
   timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \

@@ -624,6 +624,47 @@ def test_every_frame_of_four_streams_in_flight_is_the_frame(R, mode):
         c.close()
 
 
+def test_auto_order_follows_a_camera_that_creeps_stops_and_jumps(R):
+    """The library's own policy (orders used near the view they were measured on, refreshed when stale, none while the
+    view moves fast; spheres moved by rtx_update_objects age them too): 120 frames of a camera that creeps, rests, jumps
+    and races, with the spheres bouncing now and then -- every frame equals the brute kernel's frame of the same state."""
+    import torch
+    rng = np.random.default_rng(5)
+    p0, sph, pl = R.config_inputs("C2")
+    W, H = int(p0.x), int(p0.y)
+    a = R.Context(W, H)
+    b = R.Context(W, H)
+    try:
+        for c in (a, b):
+            c.set_scene(sph, pl)
+        b.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        yaw, pos = np.pi, np.zeros(3)
+        buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        ref = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        for i in range(120):
+            phase = i // 20
+            if phase in (0, 3):
+                yaw += 1.0e-4                      # creeping: an order stays usable for tens of frames
+            elif phase == 2 and i % 20 == 0:
+                yaw += 0.3                         # a jump: every order is stale at once
+                pos = rng.uniform(-2, 2, 3)
+            elif phase == 4:
+                yaw += 0.01                        # racing: no order is worth deriving
+            if phase == 5 and i % 3 == 0:
+                for c in (a, b):
+                    c.update_objects(0.05)         # the scene moves under a resting camera
+            p = R.camera_params(W, H, [float(v) for v in pos], (0.0, float(yaw), 0.0))
+            torch.cuda.synchronize()
+            a.render_rows(p, R.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0)
+            b.render_rows(p, R.RGB_ASCII, 0, H, d_out=ref.data_ptr(), out_row_base=0)
+            a.synchronize()
+            b.synchronize()
+            assert torch.equal(buf, ref), "frame %d" % i
+    finally:
+        a.close()
+        b.close()
+
+
 def test_tile_order_option_values(R, ctx):
     for ok in (-1, 0, 1, 64, 1 << 20):
         ctx.set_option(R.OPT_TILE_ORDER, ok)

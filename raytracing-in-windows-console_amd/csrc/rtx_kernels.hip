@@ -1201,9 +1201,10 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
 // the order within a class is whatever the atomics give -- any permutation renders the same frame, so only speed
 // depends on it, and every tile receives exactly one rank by construction whatever tile_cost holds).
 //
-// Why order at all: a launch's workgroups all become resident at once (7 per CU: 1792 of C2's 2040), block b on CU
-// b mod n_cu (observed: round-robin; nothing depends on it but speed), and finish when their CU has worked through
-// whatever it was dealt.  In frame order the tiles of a CU differ by 3x in work and the expensive rows come last:
+// (For grids of several dispatch rounds, and small ones; grids of one round go through rtx_balance_tiles below.)
+// Why order at all: the first 7 workgroups per CU of a launch all become resident at once (1792 of the 2040 that
+// config 2 had with 4 sub-tiles per workgroup), blocks b, b + n_cu, ... on one CU (observed: round-robin; nothing
+// depends on it but speed), and finish when their CU has worked through whatever it was dealt.  In frame order the tiles of a CU differ by 3x in work and the expensive rows come last:
 // the slowest CU takes a third longer than the average and the second-round workgroups start late and run long
 // (profiles/r02_b_stamps_sub4.txt).  So: the tiles go out heaviest first, the first `first_round` of them dealt
 // boustrophedon over the CUs (round k ascending for even k, descending for odd k) so that every CU's share

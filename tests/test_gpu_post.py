@@ -105,7 +105,13 @@ def test_update_is_the_reference_update(R, ctx):
 
 def test_update_objects_matches_oracle_over_many_steps(R, ctx):
     """Sphere::Update (Sphere.cu:15-23) with double dt, through several bounces; 1500 spheres so the
-    launch shape that breaks the reference past 1024 objects is exercised."""
+    launch shape that breaks the reference past 1024 objects is exercised.
+
+    Sphere::Update is declared with a `long double dt` parameter (Sphere.cu:15).  In device code -- where the reference
+    calls it, from the UpdateObjects kernel (RayTracingManager.cu:10-44) -- `long double` IS `double` (CUDA and HIP
+    alike have no 80-bit type on the device), and the caller passes a double anyway (RayTracingManager.cu:76,103).
+    So both the oracle and the kernel evaluate y += (double)(speed * mover) * dt in binary64: that is the reference's
+    device arithmetic, not a simplification; an x87 host evaluation would differ and is not what the reference runs."""
     rng = np.random.default_rng(7)
     n = 1500
     sph = np.concatenate([rng.uniform(-40, 40, (n, 3)), rng.uniform(0.5, 3, (n, 1)), np.floor(rng.uniform(1, 256, (n, 3)))],

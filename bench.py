@@ -1,44 +1,57 @@
 #!/usr/bin/env python3
 """bench.py -- Mrays/s (primary rays) of the ray-trace hot path on MI355X.
 
-Contract (one JSON line on rank 0):
+Contract (one JSON line on stdout, printed by rank 0):
   python bench.py --gpus N --steps K --warmup W
-  N > 1: launched by torch.distributed.run, one rank per GPU, backend nccl (= RCCL).
+  N > 1: one rank per GPU over RCCL.  Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+         environment) it runs as that rank.  Started plainly -- `python bench.py --gpus N`, no WORLD_SIZE -- the process
+         launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a CHILD process, before it
+         has imported torch or made any GPU call (never an exec of a process that touched the GPU), relays rank 0's JSON
+         line and exits with the child's exit code.
 
-Workload: BASELINE.json configs[1] -- 1920x1080, 1024 spheres + 1 plane (SURVEY.md App. D scene,
-LCG seed 2), mode RGB_ASCII (20-byte records).  A step is one frame: primary-ray generation,
-closest hit over the scene, shading and the ANSI record write for every pixel, complete character
-buffer resident in HBM at the end.  rays per frame = (W-1)*H (RayTracing.cu:187).
+Workload: BASELINE.json configs[1] -- 1920x1080, 1024 spheres + 1 plane (SURVEY.md App. D scene, LCG seed 2), mode
+RGB_ASCII (20-byte records).  A step is one frame: primary-ray generation, closest hit over the scene, shading and the
+ANSI record write for every pixel, complete character buffer resident in HBM at the end.  rays per frame = (W-1)*H
+(RayTracing.cu:187).
 
-N = 1: each frame is rendered by one launch; by default 4 frames are in flight on 4 HIP streams (frame i in
-       frame buffer i % 4), because consecutive frames are independent and the drain of one launch overlaps
-       the ramp of the next.  --frames-in-flight 1 renders strictly one after the other.
-N > 1: every frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H/N) with the global
-       row index in ray generation) and assembled, complete, in the HBM of its root GPU.  The root rotates
-       (frame i on rank i % N), so every directed xGMI link carries one slab per N frames.  Default
-       (--exchange rounds): frames go in rounds of N; a rank queues its N slab launches of a round on
-       several streams and ONE RCCL all-to-all per round delivers slab j of every rank to rank j in row
-       order.  --exchange p2p: one point-to-point gather per frame (--root fixed pins the root to rank 0).
-       Total work is fixed as N grows ("strong").  Buffers are rings, so the exchange of a round overlaps
-       the trace of the next; all K frames are complete inside the timed region.
+N = 1: each frame is rendered by one launch; by default 4 frames are in flight on 4 HIP streams (frame i in frame buffer
+       i % 4), because consecutive frames are independent and the drain of one launch overlaps the ramp of the next.
+       --frames-in-flight 1 renders strictly one after the other.
+N > 1: every frame is sharded by pixel rows (rank g renders rows [g*H/N, (g+1)*H/N) with the global row index in ray
+       generation) and assembled, complete, in the HBM of its root GPU.  The root rotates (frame i on rank i % N), so
+       every directed xGMI link carries one slab per N frames.  Default (--exchange compact): frames go in rounds of M*N;
+       a rank queues its slab launches of a round on several streams and ONE RCCL all-to-all per round delivers the slabs
+       (4-byte pixel words, expanded into records on the root).  --exchange p2p: one point-to-point gather per frame
+       (--root fixed pins the root to rank 0).  Total work is fixed as N grows ("strong").  The line also carries
+       "cpu_baseline" (rank 0, after the ranks are done) and "configs": {"C4": ...}: BASELINE config 4 (7680x4320, 1024
+       spheres: at N = 8 the eight 540-row slabs of SURVEY 8(e)) through the same loop, with its own ms_per_step,
+       verified_against_golden and roofline.
 
-Timing (N = 1): after the run-in and the W warm-up steps, a batch of exactly K steps is timed with HIP events
-(recorded on the stream(s) the kernels are launched on: every render stream stamps the start of its first frame of
-the batch and the end of its last one; the batch took from the earliest start to the latest end) and bracketed by
-synchronisation on both sides; the batch is repeated until at least --min-timed-ms of GPU time has been measured and the MEDIAN batch
-is reported ("timing" says how many repeats, their spread, and the wall-clock figure beside it).  The last frame
-of the last batch is then compared (SHA-256 of the whole 20*W*H buffer) with the committed golden value,
-outside the timed region: "verified_against_golden".
+Timing (N = 1): after the run-in and the W warm-up steps, a batch of exactly K steps is timed with HIP events (recorded on
+the stream(s) the kernels are launched on: every render stream stamps the start of its first frame of the batch and the
+end of its last one; the batch took from the earliest start to the latest end) and bracketed by synchronisation on both
+sides; the batch is repeated until at least --min-timed-ms of GPU time has been measured and the MEDIAN batch is reported
+("timing" says how many repeats, their spread, and the wall-clock figure beside it).  The last frame of the last batch is
+then compared (SHA-256 of the whole 20*W*H buffer) with the committed golden value, outside the timed region:
+"verified_against_golden".  "timing.moving_view" is the same K-frame batch with a camera that turns 0.001 rad per frame
+(no two frames alike), frames in flight and one launch at a time: what the static view's learned dispatch order is worth.
 
-Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the executed-VALU
-utilisation from the committed rocprofv3 counters, since this path is VALU-issue bound, not HBM bound) and
-"cpu_baseline" (the CPU oracle -- a structure-faithful port of the reference's loop -- timed on this host's
-cores on full frames of the same workload).
+Also reported: "roofline" (algorithmic HBM bytes / measured kernel time vs 8 TB/s, plus the executed-VALU utilisation from
+the committed rocprofv3 counters -- used only while the library sources still hash to what was profiled -- since this
+path is VALU-issue bound, not HBM bound) and "cpu_baseline" (the CPU oracle -- a structure-faithful port of the reference's
+loop -- timed on this host's cores on full frames of the same workload).
+
+--dry (tests only): the N > 1 loops over gloo with CPU tensors and the CPU oracle standing in for the HIP renderer, so that
+the launch, exchange and line-assembly code can be exercised on a machine without a GPU.  Its line says "dry": true and is
+not a measurement.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,10 +60,12 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-BASELINE_METRIC = "Mrays/s (primary rays) at 1920\u00d71080, 1024 spheres; 1/2/4/8 GPU"   # BASELINE.json "metric", verbatim
+PKG = "raytracing-in-windows-console_amd"
+BASELINE_METRIC = "Mrays/s (primary rays) at 1920×1080, 1024 spheres; 1/2/4/8 GPU"   # BASELINE.json "metric", verbatim
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak counts FMA as 2; this path may not contract, so 78.65 Tops/s
 VALU_PEAK_TLANEOPS = VALU_PEAK_TFLOPS / 2.0   # lane-operations per second when no instruction is an FMA
+MOVING_STEP_RAD = 0.001      # timing.moving_view: the camera's yaw changes by this much from every frame to the next
 
 
 def median(xs):
@@ -59,15 +74,41 @@ def median(xs):
     return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
 
 
-def committed_counters(config, mode_name, kernel):
-    """Per-launch rocprofv3 PMC averages of this kernel from profiles/counters.json (written by
-    tools/make_counters.py from the committed *_summary.json of the same bench command); None when absent."""
-    path = os.path.join(ROOT, "profiles", "counters.json")
+def csrc_sha256(root=ROOT):
+    """SHA-256 over the product library's sources (csrc/* and include/rtx.h, names and contents, sorted): what a
+    rocprofv3 summary was taken of.  tools/summarize_prof.py stores it with the counters; here it decides whether the
+    committed counters still describe the kernels that are being timed."""
+    h = hashlib.sha256()
+    d = os.path.join(root, PKG, "csrc")
+    paths = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".cpp", ".h", ".hpp", ".inc")))
+    paths.append(os.path.join(root, "include", "rtx.h"))
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()
+
+
+def committed_counters(config, mode_name, kernel, root=ROOT):
+    """(entry, note): per-launch rocprofv3 PMC averages of this kernel from profiles/counters.json (written by
+    tools/make_counters.py from the committed *_summary.json of the same bench command).  The entry is used only if it
+    carries the hash of the sources it was profiled on and that hash is the current one: a kernel edit that keeps the
+    kernel's name must not report stale counters.  (None, why) otherwise."""
+    path = os.path.join(root, "profiles", "counters.json")
     try:
         with open(path) as f:
-            return json.load(f).get("%s_%s_%s" % (config, mode_name, kernel))
+            entry = json.load(f).get("%s_%s_%s" % (config, mode_name, kernel))
     except (OSError, ValueError):
-        return None
+        return None, "profiles/counters.json missing or unreadable"
+    if not entry:
+        return None, "no committed counters for this config / mode / kernel"
+    want = entry.get("csrc_sha256")
+    if not want:
+        return None, "committed counters carry no source hash (taken before round 3): not used"
+    if want != csrc_sha256(root):
+        return None, "committed counters were taken on other sources (csrc hash %s..., now %s...): not used" % (want[:12], csrc_sha256(root)[:12])
+    return entry, None
 
 
 def algorithmic_bytes(W, H, S, ns, npl, rows=None):
@@ -81,23 +122,37 @@ def algorithmic_flops(W, H, ns, npl, hit_frac):
     return (W - 1) * H * (19.0 * ns + 7.0 * npl + 30.0 + 150.0 * hit_frac)
 
 
+_GOLDEN = None
+
+
+def golden():
+    global _GOLDEN
+    if _GOLDEN is None:
+        try:
+            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                _GOLDEN = json.load(f)
+        except OSError:
+            _GOLDEN = {}
+    return _GOLDEN
+
+
 def _frame_matches_golden(frame, config, mode_name):
     """SHA-256 of the whole frame buffer against tests/golden/golden.json (oracle-generated; no oracle needed here)."""
-    import hashlib
-    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
-        g = json.load(f).get("%s_%s" % (config, mode_name), {})
-    want = g.get("frame_sha256")
+    want = golden().get("%s_%s" % (config, mode_name), {}).get("frame_sha256")
     if not want:
         return None   # no golden frame for this config / mode
     return hashlib.sha256(frame.tobytes()).hexdigest() == want
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--config", default="C2", help="BASELINE config name (C1..C5); the graded line uses C2")
+    ap.add_argument("--config", default=None, help="BASELINE config name (C1..C5); the graded line uses C2 (the default; C1 with --dry)")
+    ap.add_argument("--sub-configs", default=None,
+                    help="N>1: comma-separated configs that get a sub-record under \"configs\" after the main measurement "
+                         "(default: C4 when the main config is C2; none with --dry; 'none' = none)")
     ap.add_argument("--mode", default="RGB_ASCII")
     ap.add_argument("--kernel", default="auto", choices=["auto", "brute", "binned"])
     ap.add_argument("--tile", type=int, default=0)
@@ -109,6 +164,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--verify", action="store_true", help="(default) check the last frame against the golden hash, outside the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the byte check of the last frame")
+    ap.add_argument("--no-moving-view", action="store_true", help="N=1: skip the timing.moving_view leg")
     ap.add_argument("--min-timed-ms", type=float, default=50.0,
                     help="N=1: the K-step batch is repeated until this much GPU time has been measured; the median batch is reported")
     ap.add_argument("--max-repeats", type=int, default=2000)
@@ -132,40 +188,141 @@ def main():
     ap.add_argument("--what", default="trace", choices=["trace", "update", "update-async"],
                     help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
-    args = ap.parse_args()
+    ap.add_argument("--dry", action="store_true",
+                    help="tests only: N>1 over gloo with CPU tensors and the CPU oracle as the renderer (no GPU, not a measurement)")
+    args = ap.parse_args(argv)
+    if args.config is None:
+        args.config = "C1" if args.dry else "C2"
+    return args
 
-    import numpy as np
-    import torch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n_gpus = args.gpus
-    # RTX_BENCH_FORCE_DIST=1 under torch.distributed.run with one rank walks the N>1 code (RCCL init, rings,
-    # all-reduce of the time) on a one-GPU box; the numbers it prints are not a bench line
-    distributed = world > 1 or os.environ.get("RTX_BENCH_FORCE_DIST") == "1"
-    if distributed and world != n_gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (n_gpus, world))
-    if not distributed and n_gpus != 1:
-        raise SystemExit("--gpus %d needs torch.distributed.run (one rank per GPU)" % n_gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    torch.cuda.set_device(local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    R = importlib.import_module("raytracing-in-windows-console_amd")
-    sharding = importlib.import_module("raytracing-in-windows-console_amd.sharding")
-    mode = R.MODE_NAMES.index(args.mode)
-    S = R.SIZE_RGB if mode >= R.RGB_ASCII else R.SIZE_8BIT
-    W, H, ns, npl, seed = R.CONFIGS[args.config]
-    params, sph, pl = R.config_inputs(args.config)
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child process (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1), relay rank 0's JSON line and return the child's exit code.  Nothing in this
+    process has imported torch or touched the GPU, and nothing will: it only waits."""
+    nproc = max(1, args.gpus)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // nproc)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    out, _ = proc.communicate()
+    line = None
+    for ln in out.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and s.endswith("}"):
+            try:
+                if "metric" in json.loads(s):
+                    line = s
+                    continue
+            except ValueError:
+                pass
+        if s:
+            sys.stderr.write(ln + "\n")   # anything else the ranks printed
+    if line is not None:
+        print(line)
+        sys.stdout.flush()
+    elif proc.returncode == 0:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        return 1
+    return proc.returncode
 
-    ctx = R.Context(W, H, device=local_rank)
-    ctx.set_scene(sph, pl)
+
+def cpu_baseline_leg(config, mode, threads_arg):
+    """The CPU oracle (oracle/: a structure-faithful port of the reference's per-pixel loop, gcc -O2 -ffp-contract=off)
+    timed on this host's cores on full frames of the same scene and mode.  A reported baseline, not the target."""
+    import oracle as O
+    import util as U
+    R = importlib.import_module(PKG)
+    W, H, ns, npl, seed = R.CONFIGS[config]
+    params, sph, pl = R.config_inputs(config)
+    rays_per_frame = (W - 1) * H
+    threads = threads_arg or min(os.cpu_count() or 1, 16)
+    sc = O.Scene.from_arrays(sph, pl)
+    op = U.oracle_params(params)
+    reps = 3 if rays_per_frame <= 4_000_000 else 1   # SURVEY 8(d): median of >= 3 frames (1 for the big configs)
+    times = []
+    for _ in range(reps):
+        t1 = time.perf_counter()
+        O.render(op, sc, mode, threads=threads)
+        times.append(time.perf_counter() - t1)
+    dt = sorted(times)[len(times) // 2]
+    cpu = {"value": round(rays_per_frame / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "sample": "%d full %dx%d frame(s) of the same scene and mode (median), row-block partition over %d threads, "
+                     "gcc -O2 -ffp-contract=off; %.2f s wall per frame" % (reps, W, H, threads, dt)}
+    if threads > 1 and rays_per_frame <= 4_000_000:
+        # SURVEY 8(d) asks for T=1 beside T=all; the middle quarter of the rows keeps it to ~1 s
+        rows1 = max(8, (H // 4) // 8 * 8)
+        t1 = time.perf_counter()
+        O.render(op, sc, mode, threads=1, row0=(H - rows1) // 2, rows=rows1)
+        dt1 = time.perf_counter() - t1
+        cpu["single_thread"] = {"value": round((W - 1) * rows1 / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
+                                "sample": "rows %d..%d of the same frame; %.2f s wall" % ((H - rows1) // 2, (H - rows1) // 2 + rows1, dt1)}
+    return cpu
+
+
+def roofline_object(config, mode_name, kernel, W, H, S_written, ns, npl, my_rows, kernel_ms, hit_frac):
+    """The "roofline" object of the line for one kernel launch: algorithmic bytes over the live kernel time
+    against the HBM peak, PMC traffic and executed-VALU utilisation from the committed counters when they are current."""
+    bytes_alg = algorithmic_bytes(W, H, S_written, ns, npl, my_rows)
+    achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters of the committed profile of this same kernel
+    # (profiles/counters.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none (or stale).
+    ctr, why = committed_counters(config, mode_name, kernel) if my_rows == H else (None, "a row slab, not the profiled whole-frame launch")
+    traffic = round(ctr["total_bytes"]) if ctr and ctr.get("total_bytes") else None
+    flops = algorithmic_flops(W, H, ns, npl, hit_frac) * (my_rows / float(H))
+    # second view: this path is bound by VALU issue, not by HBM.  Executed utilisation from the committed
+    # rocprofv3 counters of this same kernel and workload: SQ_INSTS_VALU wave-instructions x 64 lanes per
+    # launch / kernel time / 78.65 T lane-ops/s (the fp32 vector peak with no FMA: -ffp-contract=off).
+    valu = None
+    if ctr and ctr.get("SQ_INSTS_VALU"):
+        lane_ops = ctr["SQ_INSTS_VALU"] * 64.0
+        valu = {"executed_wave_instructions_per_launch": round(ctr["SQ_INSTS_VALU"]), "lane_ops_per_launch": lane_ops,
+                "achieved": round(lane_ops / (kernel_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
+                "frac": round(lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 5),
+                "source": ctr.get("source"),
+                "note": "executed VALU instructions (PMC) x 64 lanes over the live kernel time; the reference's all-pairs loop would "
+                        "need %.3g flops per launch (SURVEY 8(d) formula), which the culling kernel provably does not have to do" % flops}
+        if ctr.get("SQ_THREAD_CYCLES_VALU") and ctr.get("SQ_ACTIVE_INST_VALU"):
+            # active lanes per executed VALU instruction (rocprofv3's AvgNumActiveThreads), measured: the 64 above is an upper bound
+            lanes = ctr["SQ_THREAD_CYCLES_VALU"] / ctr["SQ_ACTIVE_INST_VALU"]
+            valu["active_lanes_per_instruction"] = round(lanes, 2)
+            valu["active_lane_ops_per_launch"] = ctr["SQ_INSTS_VALU"] * lanes
+    return {
+        "bound": "hbm", "kernel": kernel, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_unit": "bytes per launch (compare with bytes_per_launch)", "traffic_source": (ctr or {}).get("source"),
+        "traffic_note": why,
+        "bytes_per_launch": bytes_alg, "kernel_ms": round(kernel_ms, 5),
+        "kernel_ms_note": "one launch at a time on one stream (HIP events, median of 5 batches), as in the rocprofv3 summaries under profiles/",
+        "valu": valu,
+    }
+
+
+def moving_cameras(R, W, H, n=1000, step=MOVING_STEP_RAD, amplitude=0.25):
+    """A ring of n cameras whose yaw follows a triangle wave of +-amplitude around the default pose, `step` radians from
+    every camera to the next (also across the wrap-around): no two consecutive frames alike, the scene stays in view."""
+    import math
+    quarter = n // 4
+    assert quarter * 4 == n and abs(quarter * step - amplitude) < 1e-9
+    cams = []
+    for i in range(n):
+        k = i % n
+        tri = k if k <= quarter else (2 * quarter - k if k <= 3 * quarter else k - 4 * quarter)
+        cams.append(R.camera_params(W, H, pos=(0.0, 0.0, 0.0), rot=(0.0, float(math.pi) + tri * step, 0.0)))
+    return cams
+
+
+def apply_options(R, ctx, args):
     ctx.set_option(R.OPT_KERNEL, {"auto": R.KERNEL_AUTO, "brute": R.KERNEL_BRUTE, "binned": R.KERNEL_BINNED}[args.kernel])
     ctx.set_option(R.OPT_TILE_LOG2_W, args.tile)
     ctx.set_option(R.OPT_SUBTILES, args.subtiles)
@@ -174,88 +331,95 @@ def main():
     if args.tile_order >= -1:
         ctx.set_option(R.OPT_TILE_ORDER, args.tile_order)
 
-    ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)
+
+# ---------------------------------------------------------------------------------------------- N = 1
+
+def run_single(args, torch, R):
+    """One GPU: returns the result line (a dict)."""
+    mode = R.MODE_NAMES.index(args.mode)
+    S = R.SIZE_RGB if mode >= R.RGB_ASCII else R.SIZE_8BIT
+    W, H, ns, npl, seed = R.CONFIGS[args.config]
+    params, sph, pl = R.config_inputs(args.config)
+    ctx = R.Context(W, H, device=0)
+    ctx.set_scene(sph, pl)
+    apply_options(R, ctx, args)
+    ctx.render_rows(params, mode, 0, 1)   # uploads the scene
     ctx.synchronize()
     if args.frames_in_flight <= 0:
-        # N=1: 4 frames in flight; 6 where a frame is two dependent launches (the coarse-cell pre-pass of large scenes, then
+        # 4 frames in flight; 6 where a frame is two dependent launches (the coarse-cell pre-pass of large scenes, then
         # the trace): config 5 44.7 -> 42.7 us per frame, the other configs the same with 4 and 6
-        args.frames_in_flight = ((6 if len(sph) >= 16384 else 4) if not distributed else (4 if world > 2 else 2))
+        args.frames_in_flight = 6 if len(sph) >= 16384 else 4
     K, Wm = args.steps, args.warmup
-    bounds = sharding.row_bounds(H, world)
-    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
     frame_bytes = 20 * W * H
+    F = max(1, args.frames_in_flight)
+    streams, fbufs, inflight = None, None, []
+    if args.what == "update":
+        F = 1
 
-    kernel_ms = None
-    if not distributed:
-        F = max(1, args.frames_in_flight)
-        if args.what == "update":
-            F = 1
+        def step(i):
+            ctx.update(params, mode)
+    elif args.what == "update-async":
+        F = 1
+        hb = [ctx.host_alloc(frame_bytes) for _ in range(2)]
 
-            def step(i):
-                ctx.update(params, mode)
-        elif args.what == "update-async":
-            F = 1
-            hb = [ctx.host_alloc(frame_bytes) for _ in range(2)]
-            inflight = []
+        def step(i):
+            if len(inflight) == 2:
+                ctx.update_end(inflight.pop(0))
+            inflight.append(ctx.update_begin(params, mode, hb[i % 2][0]))
+    elif F == 1:
+        def step(i):
+            ctx.render(params, mode)
+    else:
+        # F frames in flight: frame i goes to stream i % F and frame buffer i % F.  Consecutive frames do
+        # not depend on each other, so the tail of one frame's launch (few workgroups left, SIMDs
+        # under-occupied) overlaps with the start of the next ones.  Every frame is rendered in full.
+        streams = [torch.cuda.Stream() for _ in range(F)]
+        fbufs = [torch.zeros(frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(F)]
+        torch.cuda.synchronize()
+        submit = ctx.make_submitter(params, mode, [b.data_ptr() for b in fbufs], [st.cuda_stream for st in streams])
 
-            def step(i):
-                if len(inflight) == 2:
-                    ctx.update_end(inflight.pop(0))
-                inflight.append(ctx.update_begin(params, mode, hb[i % 2][0]))
-        elif F == 1:
-            def step(i):
-                ctx.render(params, mode)
-        else:
-            # F frames in flight: frame i goes to stream i % F and frame buffer i % F.  Consecutive frames do
-            # not depend on each other, so the tail of one frame's launch (few workgroups left, SIMDs
-            # under-occupied) overlaps with the start of the next ones.  Every frame is rendered in full.
-            streams = [torch.cuda.Stream() for _ in range(F)]
-            fbufs = [torch.zeros(frame_bytes, dtype=torch.uint8, device="cuda") for _ in range(F)]
-            torch.cuda.synchronize()
+        def step(i):
+            # one frame per step; rtx_submit_frames queues it on stream i % F (one host call per frame)
+            submit(1, i % F)
 
-            submit = ctx.make_submitter(params, mode, [b.data_ptr() for b in fbufs], [st.cuda_stream for st in streams])
+    # Clock ramp: an idle MI355X needs some tens of milliseconds of work to reach its running clocks (measured:
+    # 25.3 us per frame when timing starts 5 ms after idle, 20.2 us in steady state).  So the GPU is first kept
+    # busy with the same frames for --prewarm-ms; none of this is timed or counted.
+    def drain():
+        if args.what == "update-async":
+            while inflight:
+                ctx.update_end(inflight.pop(0))
+        ctx.synchronize()
+        torch.cuda.synchronize()
 
-            def step(i):
-                # one frame per step; rtx_submit_frames queues it on stream i % F (one host call per frame)
-                submit(1, i % F)
-
-        # Clock ramp: an idle MI355X needs some tens of milliseconds of work to reach its running clocks (measured:
-        # 25.3 us per frame when timing starts 5 ms after idle, 20.2 us in steady state).  So the GPU is first kept
-        # busy with the same frames for --prewarm-ms; none of this is timed or counted.
-        def drain():
-            if args.what == "update-async":
-                while inflight:
-                    ctx.update_end(inflight.pop(0))
-            ctx.synchronize()
-            torch.cuda.synchronize()
-
-        n_pre = 0
-        t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
-            for _ in range(64):
-                step(n_pre)
-                n_pre += 1
-            drain()
-        for i in range(Wm):
-            step(i)
+    n_pre = 0
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:
+        for _ in range(64):
+            step(n_pre)
+            n_pre += 1
         drain()
+    for i in range(Wm):
+        step(i)
+    drain()
 
-        # One timed batch = exactly K steps, device-timed with HIP events on the streams the kernels run on and
-        # bracketed by synchronisation on both sides.
+    # One timed batch = exactly K steps, device-timed with HIP events on the streams the kernels run on and
+    # bracketed by synchronisation on both sides.
+    def make_timed_batch(step_fn, nstreams):
         if args.what != "trace":
             def timed_batch():       # the Update forms block on the host: wall clock is the measurement
                 t0 = time.perf_counter()
                 for i in range(K):
-                    step(i)
+                    step_fn(i)
                 drain()
                 dt = (time.perf_counter() - t0) * 1e3
                 return dt, dt
-        elif F == 1:
+        elif nstreams == 1:
             def timed_batch():
                 t0 = time.perf_counter()
                 ctx.timer_start()                     # hipEventRecord on the context's stream
                 for i in range(K):
-                    step(i)
+                    step_fn(i)
                 ev_ms = ctx.timer_stop()              # hipEventRecord + hipEventSynchronize + elapsed
                 torch.cuda.synchronize()
                 return ev_ms, (time.perf_counter() - t0) * 1e3
@@ -263,16 +427,16 @@ def main():
             # Each render stream stamps the start of its first frame of the batch and the end of its last one; the batch
             # took from the earliest start to the latest end (hipEventElapsedTime between events of different streams).
             # No stream waits for another at either end, so the window holds the K frames' launches and nothing else.
-            ev_s = [torch.cuda.Event(enable_timing=True) for _ in range(F)]
-            ev_e = [torch.cuda.Event(enable_timing=True) for _ in range(F)]
+            ev_s = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
+            ev_e = [torch.cuda.Event(enable_timing=True) for _ in range(nstreams)]
 
             def timed_batch():
                 t0 = time.perf_counter()
-                used = min(F, K)
+                used = min(nstreams, K)
                 for i in range(K):
-                    if i < F:
+                    if i < nstreams:
                         ev_s[i].record(streams[i])
-                    step(i)
+                    step_fn(i)
                 for j in range(used):
                     ev_e[j].record(streams[j])
                 for j in range(used):
@@ -280,396 +444,600 @@ def main():
                 torch.cuda.synchronize()
                 ev_ms = max(ev_s[a].elapsed_time(ev_e[b]) for a in range(used) for b in range(used))
                 return ev_ms, (time.perf_counter() - t0) * 1e3
+        return timed_batch
 
-        ev_batches, wall_batches = [], []
+    def repeat(timed_batch, min_ms):
+        evs, walls = [], []
         while True:
             e_ms, w_ms = timed_batch()
-            ev_batches.append(e_ms)
-            wall_batches.append(w_ms)
-            if len(ev_batches) >= args.max_repeats or (sum(ev_batches) >= args.min_timed_ms and len(ev_batches) >= 3):
+            evs.append(e_ms)
+            walls.append(w_ms)
+            if len(evs) >= args.max_repeats or (sum(evs) >= min_ms and len(evs) >= 3):
                 break
-        batch_ms = median(ev_batches)
-        elapsed = batch_ms * 1e-3                     # seconds per K steps, the median batch
-        timing = {"method": "HIP events on the render streams around each batch of K steps (earliest first-frame start to latest "
-                            "last-frame end), sync on both sides; median over repeated batches" if args.what == "trace" else "wall clock around each batch of K blocking steps; median",
-                  "repeats": len(ev_batches), "timed_ms_total": round(sum(ev_batches), 3),
-                  "batch_ms": {"median": round(batch_ms, 5), "min": round(min(ev_batches), 5), "max": round(max(ev_batches), 5)},
-                  "wall_ms_per_step_median": round(median(wall_batches) / K, 5)}
-        if not args.no_verify and args.what == "trace":
-            final = ctx.read_frame(frame_bytes) if F == 1 else fbufs[(K - 1) % F].cpu().numpy()
-        else:
-            final = None
-        # The dominant kernel on its own: launches one after the other on the context's stream, timed with
-        # HIP events on that stream (this is what a rocprofv3 kernel trace of --frames-in-flight 1 shows).
-        if args.what != "trace":
-            kernel_ms = elapsed / K * 1e3
-        else:
-            Kr = max(10, min(K, 100))
-            # (the context's own stream has its own dispatch order: let it settle as the render streams' did --
-            # the library balances a tile grid over its first launches on a stream, and keeps refining every 64th)
-            for _ in range(5 if F == 1 else 1000):
-                ctx.render(params, mode)
-            ctx.synchronize()
-            singles = []
-            for _ in range(5):
-                ctx.timer_start()
-                for _ in range(Kr):
-                    ctx.render(params, mode)
-                singles.append(ctx.timer_stop() / Kr)
-            kernel_ms = median(singles)
+        return evs, walls
+
+    ev_batches, wall_batches = repeat(make_timed_batch(step, F), args.min_timed_ms)
+    batch_ms = median(ev_batches)
+    elapsed = batch_ms * 1e-3                     # seconds per K steps, the median batch
+    timing = {"method": "HIP events on the render streams around each batch of K steps (earliest first-frame start to latest "
+                        "last-frame end), sync on both sides; median over repeated batches" if args.what == "trace" else "wall clock around each batch of K blocking steps; median",
+              "repeats": len(ev_batches), "timed_ms_total": round(sum(ev_batches), 3),
+              "batch_ms": {"median": round(batch_ms, 5), "min": round(min(ev_batches), 5), "max": round(max(ev_batches), 5)},
+              "wall_ms_per_step_median": round(median(wall_batches) / K, 5)}
+    final = None
+    if not args.no_verify and args.what == "trace":
+        final = ctx.read_frame(frame_bytes) if F == 1 else fbufs[(K - 1) % F].cpu().numpy()
+    # The dominant kernel on its own: launches one after the other on the context's stream, timed with
+    # HIP events on that stream (this is what a rocprofv3 kernel trace of --frames-in-flight 1 shows).
+    if args.what != "trace":
+        kernel_ms = elapsed / K * 1e3
     else:
-        import torch.distributed as dist
-        # The loop runs on a stream of its own, made torch's current stream: the collectives are ordered after it, and
-        # its handle is not 0.  (torch's default stream has handle 0, which the C ABI reads as "the context's own
-        # stream" / "no stream to join": with it neither rtx_submit_slabs' fork/join nor a graph capture would touch
-        # the stream the exchange is queued on.  Round 1's loop did exactly that; its frames only looked right because
-        # every frame of a bench run is the same frame.  The check rounds below would now catch it.)
-        stream = torch.cuda.Stream()
-        torch.cuda.set_stream(stream)
-        assert stream.cuda_stream != 0
-        if args.exchange in ("compact", "rounds"):
-            # Frames in rounds of M*N, frame m*N+j of a round assembled on rank j, ONE all-to-all per round.  The
-            # slab launches of a round go to F streams forked from / joined into torch's current stream (inside
-            # rtx_submit_slabs), which the RCCL call is ordered after.  "compact": the slabs travel as 4-byte
-            # pixel words and the root expands them into records on a side stream once the exchange is done.
-            compact = args.exchange == "compact"
-            fixed_root = args.root == "fixed"      # in-order delivery: every frame assembled on rank 0, in frame order
-            roots = [0] if fixed_root else None
-            M = 1 if not compact else (args.frames_per_root or ({2: 8, 4: 8, 8: 8} if fixed_root else {2: 8, 4: 4, 8: 4}).get(world, max(1, 16 // world)))
-            post = torch.cuda.Stream()
-            expanders = {}
-            use_graphs = [compact and args.graphs != 0]
-            slab_graphs, expand_graphs = {}, {}
-            full_mine = [None]
-            # per-frame latency: an event when a round's slab launches are queued, one when each of its frames is
-            # complete on its root (pools of timing events, reused round-robin; read after the timed region)
-            POOL = 64
-            ev_submit = [torch.cuda.Event(enable_timing=True) for _ in range(POOL)]
-            ev_done = [[torch.cuda.Event(enable_timing=True) for _ in range(max(1, M))] for _ in range(POOL)]
-            done_count = {}
-
-            class _After:
-                def __init__(self, ev):
-                    self.ev = ev
-
-                def wait(self):
-                    torch.cuda.current_stream().wait_event(self.ev)
-
-            def graph_or_none(build, on_stream, what):
-                """Records what build() queues on `on_stream` as a HIP graph; None (and no more attempts) if that fails."""
-                if not use_graphs[0]:
-                    return None
-                try:
-                    ctx.graph_begin(on_stream)
-                    try:
-                        build()
-                    finally:
-                        g = ctx.graph_end(on_stream)
-                    return ctx.graph_launcher(g, on_stream)
-                except R.RtxError as exc:
-                    sys.stderr.write("bench.py: HIP graph capture of the %s failed (%s); queueing launch by launch\n" % (what, exc))
-                    use_graphs[0] = False
-                    return None
-
-            def finish(q, b, work, mine):
-                with torch.cuda.stream(post):
-                    work.wait()   # orders `post` (only) after the exchange
-                    key = (b, len(mine))
-                    for m, segs in mine:
-                        ek = (b, m, len(mine))
-                        if ek not in expanders:
-                            expanders[ek] = ctx.make_expander(mode, pipe.recv[b].data_ptr(), pipe.frames[b][m].data_ptr(), segs, post.cuda_stream)
-                    if args.latency:
-                        # frame by frame, so that every frame's completion can be stamped (frames leave in frame order)
-                        for m, _ in mine:
-                            expanders[(b, m, len(mine))]()
-                            ev_done[q % POOL][m].record(post)
-                        done_count[q % POOL] = (q, len(mine))
-                    else:
-                        # a graph only for full rounds (the first round, untimed, is one: it fixes how many frames of a
-                        # full round are this rank's); a partial round -- K is not a multiple of the round -- is queued
-                        # launch by launch, so that nothing is recorded inside the timed region
-                        if full_mine[0] is None:
-                            full_mine[0] = len(mine)
-                        if mine and len(mine) == full_mine[0] and key not in expand_graphs:
-                            expand_graphs[key] = graph_or_none(lambda: [expanders[(b, m, len(mine))]() for m, _ in mine], post.cuda_stream, "expansions")
-                        if mine and expand_graphs.get(key) is not None:
-                            expand_graphs[key]()
-                        else:
-                            for m, _ in mine:
-                                expanders[(b, m, len(mine))]()
-                    ev = torch.cuda.Event()
-                    ev.record(post)
-                return _After(ev)
-
-            pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, frames_per_root=M,
-                                             pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
-            F = max(1, args.frames_in_flight)
-            rstreams = [torch.cuda.Stream() for _ in range(F)]
-            torch.cuda.synchronize()
-            RF = pipe.round_frames
-            submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,
-                                                  [pipe.unit(b, f).data_ptr() if rows else pipe.send[b].data_ptr() for f in range(RF)],
-                                                  [rstreams[f % F].cuda_stream for f in range(RF)], stream.cuda_stream,
-                                                  flags=R.RENDER_COMPACT if compact else 0)
-                          for b in range(pipe.nbuf)]
-
-            def render_round(q, b, nframes):
-                if args.latency:
-                    ev_submit[q % POOL].record(stream)
-                if not rows:
-                    return
-                if nframes == RF and use_graphs[0]:
-                    # a full round's slab launches (forked over the render streams, joined back) as one graph replay
-                    if b not in slab_graphs:
-                        slab_graphs[b] = graph_or_none(lambda: submitters[b](RF), stream.cuda_stream, "slab launches")
-                    if slab_graphs.get(b) is not None:
-                        slab_graphs[b]()
-                        return
-                submitters[b](nframes)
-
-            elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize,
-                                                prewarm=int(args.prewarm_ms * 40),   # ~25 us per frame on one GPU
-                                                min_total=args.min_timed_ms * 1e-3, max_repeats=min(args.max_repeats, 200))
-            n_rounds = -(-K // RF)
-            last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
-            slab0 = pipe.unit(0, 0)
-            latency = None
-            if args.latency and compact:
-                # queued -> complete on the root, for the frames of the last rounds still in the event pools
-                lat = []
-                for slot, (q, n) in done_count.items():
-                    if q0 <= q < q0 + n_rounds:
-                        for m in range(n):
-                            lat.append(ev_submit[slot].elapsed_time(ev_done[slot][m]))
-                t = torch.tensor([median(lat) if lat else -1.0, max(lat) if lat else -1.0], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                latency = {"median_ms": round(float(t[0].item()), 4), "max_ms": round(float(t[1].item()), 4),
-                           "of": "a frame, from the queueing of its round's slab launches to the complete frame on its root (HIP events; "
-                                 "worst rank); a round is %d frames" % RF}
-            exchange_note = ("frames in rounds of %d (M=%d per root), %s by one RCCL all-to-all per round; "
-                             % (RF, M, "every frame assembled on rank 0 in frame order (in-order delivery)" if fixed_root
-                                else "frame i of a round assembled on rank i %% N")) + \
-                            ("slabs travel as 4-byte pixel words, the root expands them into records (rtx_expand)" if compact
-                             else "slabs travel as records") + ("; HIP graph per round" if use_graphs[0] and slab_graphs else "")
-        else:
-            pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
-
-            def render(buf, r0, nrows, base):
-                # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
-                # RCCL transfers are ordered after.
-                ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
-
-            elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize,
-                                            prewarm=int(args.prewarm_ms * 40),
-                                            min_total=args.min_timed_ms * 1e-3, max_repeats=min(args.max_repeats, 200))
-            last_frame = K - 1
-            slab0 = pipe.slabs[0] if pipe.slabs is not None else None
-            exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
-        final = None
-        wins = getattr(pipe, "timed_windows", [elapsed])
-        timing = {"method": "wall clock around exactly K frames, barrier + synchronize on both sides, MAX over ranks; the window is repeated "
-                            "(each time from a drained pipeline) and the median window reported",
-                  "repeats": len(wins), "timed_ms_total": round(sum(wins) * 1e3, 3),
-                  "batch_ms": {"median": round(elapsed * 1e3, 5), "min": round(min(wins) * 1e3, 5), "max": round(max(wins) * 1e3, 5)}}
-        dist_verified = None
-        if not args.no_verify:
-            # byte check of the last assembled frame, outside the timed region: its root hashes it (SHA-256 of the
-            # whole 20*W*H buffer against the committed golden value); the verdict is reduced to rank 0 as a
-            # tri-state: 1 = compared and equal, 0 = compared and different (or the check itself failed),
-            # 2 = no golden value for this config / mode, nothing compared
-            code = 2
-            try:
-                if rank == pipe.root_of(last_frame):
-                    m = _frame_matches_golden(pipe.frame(last_frame).cpu().numpy(), args.config, args.mode)
-                    code = 2 if m is None else int(bool(m))
-            except Exception as exc:   # a failed check must not lose the measurement, but it must be seen
-                sys.stderr.write("bench.py: golden check of frame %d failed on rank %d: %r\n" % (last_frame, rank, exc))
-                code = 0
-            flag = torch.tensor([code], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            dist_verified = {0: False, 1: True}.get(int(flag.item()))   # None: no rank compared anything
-        # ---- check rounds, outside the timed region: is every frame that arrives on a root the frame its camera
-        # renders?  (a) the send buffers are poisoned and one more round goes through the very path that was timed
-        # (graph replays included): a slab that was not rendered again, or exchanged before it was rendered, shows as
-        # poison; (b) a round in which every frame has its own camera, queued launch by launch: a slab that lands in the
-        # wrong frame or on the wrong root shows.  Each root compares its frames on the GPU with the whole frame it
-        # renders itself for the same camera.
-        rounds_ok = None
-        if args.exchange in ("compact", "rounds") and not args.no_verify:
-            code = 1
-            try:
-                qn = q0 + n_rounds
-                tmp = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
-
-                def frame_is(i, p_i):
-                    ctx.render_rows(p_i, mode, 0, H, d_out=tmp.data_ptr(), out_row_base=0, stream=stream.cuda_stream,
-                                    flags=0 if mode >= R.RGB_ASCII else R.RENDER_ZERO_TAIL)
-                    torch.cuda.synchronize()
-                    return bool(torch.equal(pipe.frame(i)[:S * W * H], tmp[:S * W * H]))
-
-                for b in range(pipe.nbuf):
-                    pipe.send[b].fill_(0xEE)
-                for r in range(pipe.nbuf):
-                    pipe.round(qn + r, RF, render_round)
-                pipe.drain()
-                torch.cuda.synchronize()
-                for r in range(pipe.nbuf):
-                    for f in range(RF):
-                        i = (qn + r) * RF + f
-                        if pipe.root_of(i) == rank and not frame_is(i, params):
-                            sys.stderr.write("bench.py: rank %d: frame %d of a poisoned round differs from the frame rendered in one piece\n" % (rank, i))
-                            code = 0
-                qn += pipe.nbuf
-                cams = [R.camera_params(W, H, pos=(0.03 * f, 0.01 * f, 0.0), rot=(0.0, float(np.float32(np.pi)) + 0.002 * f, 0.0)) for f in range(RF)]
-
-                def render_round_cams(q, b, nframes):
-                    if rows:
-                        ctx.submit_slabs(cams[:nframes], mode, row0, rows, [pipe.unit(b, f).data_ptr() for f in range(nframes)], row0,
-                                         [rstreams[f % F].cuda_stream for f in range(nframes)], after=stream.cuda_stream,
-                                         flags=R.RENDER_COMPACT if compact else 0)
-
-                pipe.round(qn, RF, render_round_cams)
-                pipe.drain()
-                torch.cuda.synchronize()
-                for f in range(RF):
-                    i = qn * RF + f
-                    if pipe.root_of(i) == rank and not frame_is(i, cams[f]):
-                        sys.stderr.write("bench.py: rank %d: frame %d (own camera) differs from the frame rendered in one piece\n" % (rank, i))
-                        code = 0
-            except Exception as exc:
-                sys.stderr.write("bench.py: check rounds failed on rank %d: %r\n" % (rank, exc))
-                code = 0
-            flag = torch.tensor([code], dtype=torch.int32, device="cuda")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            rounds_ok = bool(flag.item())
-            if rounds_ok is False:
-                dist_verified = False
-            timing["check_rounds"] = {"passed": rounds_ok,
-                                      "what": "after the timed region: %d round(s) through the timed path with poisoned send buffers, one round with a camera "
-                                              "per frame; every root compares its frames with the same frames rendered in one piece" % pipe.nbuf}
-        if args.exchange in ("compact", "rounds") and latency is not None:
-            timing["frame_latency"] = latency
-        # per-rank kernel time, measured apart from the pipeline, for the roofline object
+        Kr = max(10, min(K, 100))
+        # (the context's own stream has its own dispatch order: let it settle as the render streams' did --
+        # the library balances a tile grid over its first launches on a stream, and keeps refining every 64th)
+        for _ in range(5 if F == 1 else 1000):
+            ctx.render(params, mode)
         ctx.synchronize()
-        ctx.timer_start()
-        for _ in range(min(K, 50)):
-            tgt = slab0 if slab0 is not None else pipe.frames[0]
-            ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0,
-                            flags=R.RENDER_COMPACT if args.exchange == "compact" else 0)
-        kernel_ms = ctx.timer_stop() / min(K, 50)
+        singles = []
+        for _ in range(5):
+            ctx.timer_start()
+            for _ in range(Kr):
+                ctx.render(params, mode)
+            singles.append(ctx.timer_stop() / Kr)
+        kernel_ms = median(singles)
+
+    # timing.moving_view: the same K-frame batches with a camera that turns MOVING_STEP_RAD per frame (a ring of 1000
+    # views, +-0.25 rad around the default pose), F frames in flight and one launch at a time.  The dispatch order the
+    # library learns on a static view (rtx_balance_tiles) has nothing to learn from here; these are the rates a caller
+    # whose camera never rests sees.  Outside the graded number, after the verification copy.
+    if args.what == "trace" and not args.no_moving_view:
+        NMV = 1000
+        cams = moving_cameras(R, W, H, NMV)
+        counter = [0]
+        mv = {"step_rad_per_frame": MOVING_STEP_RAD, "views": NMV,
+              "what": "batches of the same K frames, yaw on a triangle wave of +-0.25 rad, every frame %g rad from the one before" % MOVING_STEP_RAD}
+        if F > 1:
+            ring = ctx.make_submitter(cams, mode, [fbufs[i % F].data_ptr() for i in range(NMV)], [streams[i % F].cuda_stream for i in range(NMV)])
+
+            def step_mv(i):
+                # frame buffer / stream i % F as in the static batch (NMV is a multiple of F or the ring position decides)
+                ring(1, counter[0] % NMV)
+                counter[0] += 1
+            if NMV % F == 0:
+                for i in range(200):
+                    step_mv(i)
+                drain()
+                counter[0] = 0   # batches start on stream 0, as the event bookkeeping assumes
+                evs, _ = repeat(make_timed_batch(lambda i: (ring(1, (counter[0] + i) % NMV)), F), min(args.min_timed_ms, 30.0))
+                # (every batch replays views counter[0] .. counter[0]+K-1; advancing by K keeps ring position % F == i % F only
+                # when K % F == 0, so the batches all start at view 0: K consecutive views, each a step from the last)
+                mv["in_flight_ms_per_frame"] = round(median(evs) / K, 5)
+                mv["frames_in_flight"] = F
+
+        def step_alone(i):
+            ctx.render(cams[counter[0] % NMV], mode)
+            counter[0] += 1
+        counter[0] = 0
+        for i in range(200):
+            step_alone(i)
+        ctx.synchronize()
+        alone = []
+        for _ in range(5):
+            ctx.timer_start()
+            for i in range(max(10, min(K, 200))):
+                step_alone(i)
+            alone.append(ctx.timer_stop() / max(10, min(K, 200)))
+        mv["alone_ms_per_frame"] = round(median(alone), 5)
+        mv["static_in_flight_ms_per_frame"] = round(elapsed / K * 1e3, 5)
+        mv["static_alone_ms_per_frame"] = round(kernel_ms, 5)
+        timing["moving_view"] = mv
 
     rays_per_frame = (W - 1) * H
     mrays = rays_per_frame * K / elapsed / 1e6
-
-    out = None
-    if rank == 0:
-        gold = {}
-        try:
-            with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
-                gold = json.load(f)
-        except OSError:
-            pass
-        g = gold.get("%s_%s" % (args.config, args.mode), {})
-        hit_frac = (g.get("foreground_pixels") or 0) / float(rays_per_frame)
-        verified = dist_verified if distributed else None
-        if final is not None:
-            verified = _frame_matches_golden(final, args.config, args.mode)
-
-        my_rows = rows
-        # the trace kernel of a rank writes S bytes per pixel, or 4 when the slabs travel as pixel words
-        bytes_alg = algorithmic_bytes(W, H, 4 if (distributed and args.exchange == "compact") else S, ns, npl, my_rows)
-        achieved_gbs = bytes_alg / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC counters of the committed profile of this same kernel
-        # (profiles/counters.json: WRITE_SIZE + 2*FETCH_SIZE, the gfx950 correction); null when there is none.
-        traffic = None
-        traffic_detail = committed_counters(args.config, args.mode, ctx.last_kernel) if my_rows == H else None
-        if traffic_detail and traffic_detail.get("total_bytes"):
-            traffic = round(traffic_detail["total_bytes"])
-        flops = algorithmic_flops(W, H, ns, npl, hit_frac) * (my_rows / float(H))
-        # second view: this path is bound by VALU issue, not by HBM.  Executed utilisation from the committed
-        # rocprofv3 counters of this same kernel and workload: SQ_INSTS_VALU wave-instructions x 64 lanes per
-        # launch / kernel time / 78.65 T lane-ops/s (the fp32 vector peak with no FMA: -ffp-contract=off).
-        ctr = committed_counters(args.config, args.mode, ctx.last_kernel) if my_rows == H else None
-        valu = None
-        if ctr and ctr.get("SQ_INSTS_VALU"):
-            lane_ops = ctr["SQ_INSTS_VALU"] * 64.0
-            valu = {"executed_wave_instructions_per_launch": round(ctr["SQ_INSTS_VALU"]), "lane_ops_per_launch": lane_ops,
-                    "achieved": round(lane_ops / (kernel_ms * 1e-3) / 1e12, 3), "peak": VALU_PEAK_TLANEOPS, "unit": "T lane-ops/s",
-                    "frac": round(lane_ops / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TLANEOPS, 5),
-                    "source": ctr.get("source"),
-                    "note": "executed VALU instructions (PMC) over the live kernel time; the reference's all-pairs loop would "
-                            "need %.3g flops per launch (SURVEY 8(d) formula), which the culling kernel provably does not have to do" % flops}
-        roofline = {
-            "bound": "hbm", "kernel": ctx.last_kernel, "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_unit": "bytes per launch (compare with bytes_per_launch)", "traffic_source": (traffic_detail or {}).get("source"),
-            "bytes_per_launch": bytes_alg, "kernel_ms": round(kernel_ms, 5),
-            "kernel_ms_note": "one launch at a time on one stream (HIP events, median of 5 batches), as in the rocprofv3 summaries under profiles/",
-            "valu": valu,
-        }
-
-        cpu = None
-        if not args.no_cpu_baseline and not distributed:
-            import oracle as O
-            import util as U
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
-            sc = O.Scene.from_arrays(sph, pl)
-            op = U.oracle_params(params)
-            reps = 3 if rays_per_frame <= 4_000_000 else 1   # SURVEY 8(d): median of >= 3 frames (1 for the big configs)
-            times = []
-            for _ in range(reps):
-                t1 = time.perf_counter()
-                O.render(op, sc, mode, threads=threads)
-                times.append(time.perf_counter() - t1)
-            dt = sorted(times)[len(times) // 2]
-            cpu = {"value": round(rays_per_frame / dt / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                   "sample": "%d full %dx%d frame(s) of the same scene and mode (median), row-block partition over %d threads, "
-                             "gcc -O2 -ffp-contract=off; %.2f s wall per frame" % (reps, W, H, threads, dt)}
-            if threads > 1 and rays_per_frame <= 4_000_000:
-                # SURVEY 8(d) asks for T=1 beside T=all; the middle quarter of the rows keeps it to ~1 s
-                rows1 = max(8, (H // 4) // 8 * 8)
-                t1 = time.perf_counter()
-                O.render(op, sc, mode, threads=1, row0=(H - rows1) // 2, rows=rows1)
-                dt1 = time.perf_counter() - t1
-                cpu["single_thread"] = {"value": round((W - 1) * rows1 / dt1 / 1e6, 4), "unit": "Mrays/s", "cores": 1,
-                                        "sample": "rows %d..%d of the same frame; %.2f s wall" % ((H - rows1) // 2, (H - rows1) // 2 + rows1, dt1)}
-
-        out = {
-            "metric": BASELINE_METRIC,
-            "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
-            "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
-                                   % (args.config, W, H, ns, npl, args.mode, seed),
-                       "rays_per_frame": rays_per_frame, "kernel": ctx.last_kernel, "prewarm_ms": args.prewarm_ms,
-                       "parallelism": "1 GPU" if n_gpus == 1 else "rows sharded over %d GPUs; %s" % (n_gpus, exchange_note)},
-            "timing": timing, "roofline": roofline, "cpu_baseline": cpu,
-        }
-        if args.what != "trace":
-            out["metric"] = "Mrays/s through the whole Update (trace + minimise + D2H of the minimised stream); not the graded metric"
-            out["roofline"] = None
-        if not distributed and args.what == "trace":
-            eff_ms = elapsed / K * 1e3
-            out["config"]["frames_in_flight"] = max(1, args.frames_in_flight)
-            roofline["pipelined"] = {
-                "frames_in_flight": max(1, args.frames_in_flight), "effective_ms_per_frame": round(eff_ms, 5),
-                "achieved": round(bytes_alg / (eff_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
-                "frac": round(bytes_alg / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "whole-job rate with overlapping launches; 'achieved'/'frac' above are for one launch alone"}
-        # true / false = the last frame was compared with the committed golden SHA-256; null = nothing was compared
-        out["verified_against_golden"] = verified
-        if cpu:
-            out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
-
+    g = golden().get("%s_%s" % (args.config, args.mode), {})
+    hit_frac = (g.get("foreground_pixels") or 0) / float(rays_per_frame)
+    verified = _frame_matches_golden(final, args.config, args.mode) if final is not None else None
+    kernel = ctx.last_kernel
+    roofline = roofline_object(args.config, args.mode, kernel, W, H, S, ns, npl, H, kernel_ms, hit_frac)
     ctx.close()
-    if distributed:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-    if out is not None:
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(args.config, mode, args.cpu_threads)
+    out = {
+        "metric": BASELINE_METRIC,
+        "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": 1, "steps": K, "warmup": Wm,
+        "ms_per_step": round(elapsed / K * 1e3, 5), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
+                               % (args.config, W, H, ns, npl, args.mode, seed),
+                   "rays_per_frame": rays_per_frame, "kernel": kernel, "prewarm_ms": args.prewarm_ms,
+                   "parallelism": "1 GPU"},
+        "timing": timing, "roofline": roofline, "cpu_baseline": cpu,
+    }
+    if args.what != "trace":
+        out["metric"] = "Mrays/s through the whole Update (trace + minimise + D2H of the minimised stream); not the graded metric"
+        out["roofline"] = None
+    else:
+        eff_ms = elapsed / K * 1e3
+        out["config"]["frames_in_flight"] = F
+        roofline["pipelined"] = {
+            "frames_in_flight": F, "effective_ms_per_frame": round(eff_ms, 5),
+            "achieved": round(roofline["bytes_per_launch"] / (eff_ms * 1e-3) / 1e9, 2), "unit": "GB/s",
+            "frac": round(roofline["bytes_per_launch"] / (eff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "whole-job rate with overlapping launches; 'achieved'/'frac' above are for one launch alone"}
+    # true / false = the last frame was compared with the committed golden SHA-256; null = nothing was compared
+    out["verified_against_golden"] = verified
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(mrays / cpu["value"], 1)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- N > 1 (GPUs over RCCL)
+
+def run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, config, K, Wm, prewarm_frames):
+    """One configuration through the N > 1 loop on this rank's GPU.  Returns (on every rank) a dict with the elapsed
+    seconds per K frames (MAX over ranks, median window), the timing object, the verification verdicts, this rank's
+    slab-kernel time and the strings the line needs."""
+    import numpy as np
+    mode = R.MODE_NAMES.index(args.mode)
+    S = R.SIZE_RGB if mode >= R.RGB_ASCII else R.SIZE_8BIT
+    W, H, ns, npl, seed = R.CONFIGS[config]
+    params, sph, pl = R.config_inputs(config)
+    ctx = R.Context(W, H, device=local_rank)
+    ctx.set_scene(sph, pl)
+    apply_options(R, ctx, args)
+    ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)
+    ctx.synchronize()
+    F = args.frames_in_flight if args.frames_in_flight > 0 else (4 if world > 2 else 2)
+    bounds = sharding.row_bounds(H, world)
+    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
+    # The loop runs on a stream of its own, made torch's current stream: the collectives are ordered after it, and
+    # its handle is not 0.  (torch's default stream has handle 0, which the C ABI reads as "the context's own
+    # stream" / "no stream to join": with it neither rtx_submit_slabs' fork/join nor a graph capture would touch
+    # the stream the exchange is queued on.  Round 1's loop did exactly that; its frames only looked right because
+    # every frame of a bench run is the same frame.  The check rounds below would now catch it.)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    latency = None
+    n_rounds = q0 = RF = None
+    rstreams = None
+    compact = args.exchange == "compact"
+    if args.exchange in ("compact", "rounds"):
+        # Frames in rounds of M*N, frame m*N+j of a round assembled on rank j, ONE all-to-all per round.  The
+        # slab launches of a round go to F streams forked from / joined into torch's current stream (inside
+        # rtx_submit_slabs), which the RCCL call is ordered after.  "compact": the slabs travel as 4-byte
+        # pixel words and the root expands them into records on a side stream once the exchange is done.
+        fixed_root = args.root == "fixed"      # in-order delivery: every frame assembled on rank 0, in frame order
+        roots = [0] if fixed_root else None
+        M = 1 if not compact else (args.frames_per_root or ({2: 8, 4: 8, 8: 8} if fixed_root else {2: 8, 4: 4, 8: 4}).get(world, max(1, 16 // world)))
+        post = torch.cuda.Stream()
+        expanders = {}
+        use_graphs = [compact and args.graphs != 0]
+        slab_graphs, expand_graphs = {}, {}
+        full_mine = [None]
+        # per-frame latency: an event when a round's slab launches are queued, one when each of its frames is
+        # complete on its root (pools of timing events, reused round-robin; read after the timed region)
+        POOL = 64
+        ev_submit = [torch.cuda.Event(enable_timing=True) for _ in range(POOL)]
+        ev_done = [[torch.cuda.Event(enable_timing=True) for _ in range(max(1, M))] for _ in range(POOL)]
+        done_count = {}
+
+        class _After:
+            def __init__(self, ev):
+                self.ev = ev
+
+            def wait(self):
+                torch.cuda.current_stream().wait_event(self.ev)
+
+        def graph_or_none(build, on_stream, what):
+            """Records what build() queues on `on_stream` as a HIP graph; None (and no more attempts) if that fails."""
+            if not use_graphs[0]:
+                return None
+            try:
+                ctx.graph_begin(on_stream)
+                try:
+                    build()
+                finally:
+                    g = ctx.graph_end(on_stream)
+                return ctx.graph_launcher(g, on_stream)
+            except R.RtxError as exc:
+                sys.stderr.write("bench.py: HIP graph capture of the %s failed (%s); queueing launch by launch\n" % (what, exc))
+                use_graphs[0] = False
+                return None
+
+        def finish(q, b, work, mine):
+            with torch.cuda.stream(post):
+                work.wait()   # orders `post` (only) after the exchange
+                key = (b, len(mine))
+                for m, segs in mine:
+                    ek = (b, m, len(mine))
+                    if ek not in expanders:
+                        expanders[ek] = ctx.make_expander(mode, pipe.recv[b].data_ptr(), pipe.frames[b][m].data_ptr(), segs, post.cuda_stream)
+                if args.latency:
+                    # frame by frame, so that every frame's completion can be stamped (frames leave in frame order)
+                    for m, _ in mine:
+                        expanders[(b, m, len(mine))]()
+                        ev_done[q % POOL][m].record(post)
+                    done_count[q % POOL] = (q, len(mine))
+                else:
+                    # a graph only for full rounds (the first round, untimed, is one: it fixes how many frames of a
+                    # full round are this rank's); a partial round -- K is not a multiple of the round -- is queued
+                    # launch by launch, so that nothing is recorded inside the timed region
+                    if full_mine[0] is None:
+                        full_mine[0] = len(mine)
+                    if mine and len(mine) == full_mine[0] and key not in expand_graphs:
+                        expand_graphs[key] = graph_or_none(lambda: [expanders[(b, m, len(mine))]() for m, _ in mine], post.cuda_stream, "expansions")
+                    if mine and expand_graphs.get(key) is not None:
+                        expand_graphs[key]()
+                    else:
+                        for m, _ in mine:
+                            expanders[(b, m, len(mine))]()
+                ev = torch.cuda.Event()
+                ev.record(post)
+            return _After(ev)
+
+        pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, frames_per_root=M,
+                                         pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
+        rstreams = [torch.cuda.Stream() for _ in range(F)]
+        torch.cuda.synchronize()
+        RF = pipe.round_frames
+        submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,
+                                              [pipe.unit(b, f).data_ptr() if rows else pipe.send[b].data_ptr() for f in range(RF)],
+                                              [rstreams[f % F].cuda_stream for f in range(RF)], stream.cuda_stream,
+                                              flags=R.RENDER_COMPACT if compact else 0)
+                      for b in range(pipe.nbuf)]
+
+        def render_round(q, b, nframes):
+            if args.latency:
+                ev_submit[q % POOL].record(stream)
+            if not rows:
+                return
+            if nframes == RF and use_graphs[0]:
+                # a full round's slab launches (forked over the render streams, joined back) as one graph replay
+                if b not in slab_graphs:
+                    slab_graphs[b] = graph_or_none(lambda: submitters[b](RF), stream.cuda_stream, "slab launches")
+                if slab_graphs.get(b) is not None:
+                    slab_graphs[b]()
+                    return
+            submitters[b](nframes)
+
+        elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cuda", torch.cuda.synchronize,
+                                            prewarm=prewarm_frames,
+                                            min_total=args.min_timed_ms * 1e-3, max_repeats=min(args.max_repeats, 200))
+        n_rounds = -(-K // RF)
+        last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
+        slab0 = pipe.unit(0, 0)
+        if args.latency and compact:
+            # queued -> complete on the root, for the frames of the last rounds still in the event pools
+            lat = []
+            for slot, (q, n) in done_count.items():
+                if q0 <= q < q0 + n_rounds:
+                    for m in range(n):
+                        lat.append(ev_submit[slot].elapsed_time(ev_done[slot][m]))
+            t = torch.tensor([median(lat) if lat else -1.0, max(lat) if lat else -1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            latency = {"median_ms": round(float(t[0].item()), 4), "max_ms": round(float(t[1].item()), 4),
+                       "of": "a frame, from the queueing of its round's slab launches to the complete frame on its root (HIP events; "
+                             "worst rank); a round is %d frames" % RF}
+        exchange_note = ("frames in rounds of %d (M=%d per root), %s by one RCCL all-to-all per round; "
+                         % (RF, M, "every frame assembled on rank 0 in frame order (in-order delivery)" if fixed_root
+                            else "frame i of a round assembled on rank i %% N")) + \
+                        ("slabs travel as 4-byte pixel words, the root expands them into records (rtx_expand)" if compact
+                         else "slabs travel as records") + ("; HIP graph per round" if use_graphs[0] and slab_graphs else "")
+    else:
+        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, rotate_root=(args.root == "rotate"))
+
+        def render(buf, r0, nrows, base):
+            # root traces its own rows straight into the frame; peers into their slab.  Same stream as the
+            # RCCL transfers are ordered after.
+            ctx.render_rows(params, mode, r0, nrows, d_out=buf.data_ptr(), out_row_base=base, stream=stream.cuda_stream)
+
+        elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cuda", torch.cuda.synchronize,
+                                        prewarm=prewarm_frames,
+                                        min_total=args.min_timed_ms * 1e-3, max_repeats=min(args.max_repeats, 200))
+        last_frame = K - 1
+        slab0 = pipe.slabs[0] if pipe.slabs is not None else None
+        exchange_note = "RCCL p2p gather per frame; frame i assembled on rank %s" % ("i % N" if args.root == "rotate" else "0")
+    wins = getattr(pipe, "timed_windows", [elapsed])
+    timing = {"method": "wall clock around exactly K frames, barrier + synchronize on both sides, MAX over ranks; the window is repeated "
+                        "(each time from a drained pipeline) and the median window reported",
+              "repeats": len(wins), "timed_ms_total": round(sum(wins) * 1e3, 3),
+              "batch_ms": {"median": round(elapsed * 1e3, 5), "min": round(min(wins) * 1e3, 5), "max": round(max(wins) * 1e3, 5)}}
+    dist_verified = None
+    if not args.no_verify:
+        # byte check of the last assembled frame, outside the timed region: its root hashes it (SHA-256 of the
+        # whole 20*W*H buffer against the committed golden value); the verdict is reduced to rank 0 as a
+        # tri-state: 1 = compared and equal, 0 = compared and different (or the check itself failed),
+        # 2 = no golden value for this config / mode, nothing compared
+        code = 2
+        try:
+            if rank == pipe.root_of(last_frame):
+                m = _frame_matches_golden(pipe.frame(last_frame).cpu().numpy(), config, args.mode)
+                code = 2 if m is None else int(bool(m))
+        except Exception as exc:   # a failed check must not lose the measurement, but it must be seen
+            sys.stderr.write("bench.py: golden check of frame %d failed on rank %d: %r\n" % (last_frame, rank, exc))
+            code = 0
+        flag = torch.tensor([code], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist_verified = {0: False, 1: True}.get(int(flag.item()))   # None: no rank compared anything
+    # ---- check rounds, outside the timed region: is every frame that arrives on a root the frame its camera
+    # renders?  (a) the send buffers are poisoned and one more round goes through the very path that was timed
+    # (graph replays included): a slab that was not rendered again, or exchanged before it was rendered, shows as
+    # poison; (b) a round in which every frame has its own camera, queued launch by launch: a slab that lands in the
+    # wrong frame or on the wrong root shows.  Each root compares its frames on the GPU with the whole frame it
+    # renders itself for the same camera.
+    if args.exchange in ("compact", "rounds") and not args.no_verify:
+        code = 1
+        try:
+            qn = q0 + n_rounds
+            tmp = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+
+            def frame_is(i, p_i):
+                ctx.render_rows(p_i, mode, 0, H, d_out=tmp.data_ptr(), out_row_base=0, stream=stream.cuda_stream,
+                                flags=0 if mode >= R.RGB_ASCII else R.RENDER_ZERO_TAIL)
+                torch.cuda.synchronize()
+                return bool(torch.equal(pipe.frame(i)[:S * W * H], tmp[:S * W * H]))
+
+            for b in range(pipe.nbuf):
+                pipe.send[b].fill_(0xEE)
+            for r in range(pipe.nbuf):
+                pipe.round(qn + r, RF, render_round)
+            pipe.drain()
+            torch.cuda.synchronize()
+            for r in range(pipe.nbuf):
+                for f in range(RF):
+                    i = (qn + r) * RF + f
+                    if pipe.root_of(i) == rank and not frame_is(i, params):
+                        sys.stderr.write("bench.py: rank %d: frame %d of a poisoned round differs from the frame rendered in one piece\n" % (rank, i))
+                        code = 0
+            qn += pipe.nbuf
+            cams = [R.camera_params(W, H, pos=(0.03 * f, 0.01 * f, 0.0), rot=(0.0, float(np.float32(np.pi)) + 0.002 * f, 0.0)) for f in range(RF)]
+
+            def render_round_cams(q, b, nframes):
+                if rows:
+                    ctx.submit_slabs(cams[:nframes], mode, row0, rows, [pipe.unit(b, f).data_ptr() for f in range(nframes)], row0,
+                                     [rstreams[f % F].cuda_stream for f in range(nframes)], after=stream.cuda_stream,
+                                     flags=R.RENDER_COMPACT if compact else 0)
+
+            pipe.round(qn, RF, render_round_cams)
+            pipe.drain()
+            torch.cuda.synchronize()
+            for f in range(RF):
+                i = qn * RF + f
+                if pipe.root_of(i) == rank and not frame_is(i, cams[f]):
+                    sys.stderr.write("bench.py: rank %d: frame %d (own camera) differs from the frame rendered in one piece\n" % (rank, i))
+                    code = 0
+            del tmp
+        except Exception as exc:
+            sys.stderr.write("bench.py: check rounds failed on rank %d: %r\n" % (rank, exc))
+            code = 0
+        flag = torch.tensor([code], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rounds_ok = bool(flag.item())
+        if rounds_ok is False:
+            dist_verified = False
+        timing["check_rounds"] = {"passed": rounds_ok,
+                                  "what": "after the timed region: %d round(s) through the timed path with poisoned send buffers, one round with a camera "
+                                          "per frame; every root compares its frames with the same frames rendered in one piece" % pipe.nbuf}
+    if latency is not None:
+        timing["frame_latency"] = latency
+    # per-rank kernel time, measured apart from the pipeline, for the roofline object
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    n_k = max(10, min(K, 50))
+    tgt = slab0 if slab0 is not None else pipe.frames[0]
+    if isinstance(tgt, list):
+        tgt = tgt[0]
+    for _ in range(3):
+        ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0,
+                        flags=R.RENDER_COMPACT if compact else 0)
+    ctx.synchronize()
+    ctx.timer_start()
+    for _ in range(n_k):
+        ctx.render_rows(params, mode, row0, rows, d_out=tgt.data_ptr(), out_row_base=row0 if slab0 is not None else 0,
+                        flags=R.RENDER_COMPACT if compact else 0)
+    kernel_ms = ctx.timer_stop() / n_k
+    kernel = ctx.last_kernel
+    torch.cuda.synchronize()
+    del pipe
+    ctx.close()
+    torch.cuda.empty_cache()
+    return {"config": config, "elapsed": elapsed, "timing": timing, "verified": dist_verified, "kernel_ms": kernel_ms, "kernel": kernel,
+            "exchange_note": exchange_note, "rows": rows, "S_written": 4 if compact else S,
+            "W": W, "H": H, "ns": ns, "npl": npl, "seed": seed}
+
+
+# ---------------------------------------------------------------------------------------------- N > 1, dry (tests)
+
+def run_sharded_dry(args, torch, dist, R, sharding, rank, world, config, K, Wm):
+    """The N > 1 loops over gloo with CPU tensors; the CPU oracle renders (there is no GPU): same sharding classes, same
+    timing functions, same verification as run_sharded, so that launch, exchange and line assembly can be tested on CPU."""
+    import numpy as np
+    import oracle as O
+    import util as U
+    mode = R.MODE_NAMES.index(args.mode)
+    S = R.SIZE_RGB if mode >= R.RGB_ASCII else R.SIZE_8BIT
+    W, H, ns, npl, seed = R.CONFIGS[config]
+    params, sph, pl = R.config_inputs(config)
+    sc = O.Scene.from_arrays(sph, pl)
+    op = U.oracle_params(params)
+    compact = args.exchange == "compact"
+    hit_kind = ord("3") if args.mode.endswith("ASCII") else ord("4")
+    bounds = sharding.row_bounds(H, world)
+    row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
+    my_slab = O.render(op, sc, mode, row0=row0, rows=rows)[row0 * W * S:(row0 + rows) * W * S]   # every frame is this frame
+    my_words = U.records_to_words(my_slab, W, rows, S) if compact and rows else None
+    q0 = n_rounds = RF = None
+    if args.exchange in ("compact", "rounds"):
+        fixed_root = args.root == "fixed"
+        roots = [0] if fixed_root else None
+        M = 1 if not compact else (args.frames_per_root or 2)
+
+        def finish(q, b, work, mine):
+            # stands in for "wait on a side stream, then rtx_expand": words -> records, segment by segment
+            work.wait()
+            for m, segs in mine:
+                words = pipe.recv[b].numpy().view(np.uint32)
+                dst = pipe.frames[b][m].numpy()
+                for src_px, dst_px, n in segs:
+                    dst[dst_px * S:(dst_px + n) * S] = U.words_to_records(words[src_px:src_px + n], S, hit_kind)
+            return None
+
+        pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cpu", nbuf=2, frames_per_root=M,
+                                         pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
+        RF = pipe.round_frames
+
+        def render_round(q, b, nframes):
+            for f in range(nframes):
+                if rows:
+                    if compact:
+                        pipe.unit(b, f).numpy().view(np.uint32)[:] = my_words
+                    else:
+                        pipe.unit(b, f).numpy()[:] = my_slab
+
+        elapsed, q0 = sharding.timed_rounds(dist, torch, pipe, render_round, K, Wm, "cpu", lambda: None, prewarm=0,
+                                            min_total=0.0, max_repeats=1)
+        n_rounds = -(-K // RF)
+        last_frame = (q0 + n_rounds - 1) * RF + (K - 1 - (n_rounds - 1) * RF)
+        exchange_note = "dry: rounds of %d frames over gloo, %s" % (RF, "compact words" if compact else "records")
+    else:
+        pipe = sharding.RowShardedFrames(dist, torch, rank, world, W, H, S, "cpu", nbuf=2, rotate_root=(args.root == "rotate"))
+
+        def render(buf, r0, nrows, base):
+            buf.numpy()[(r0 - base) * W * S:(r0 - base + nrows) * W * S] = my_slab
+
+        elapsed = sharding.timed_frames(dist, torch, pipe, render, K, Wm, "cpu", lambda: None, prewarm=0, min_total=0.0, max_repeats=1)
+        last_frame = K - 1
+        exchange_note = "dry: p2p gather per frame over gloo"
+    wins = getattr(pipe, "timed_windows", [elapsed])
+    timing = {"method": "dry run: wall clock around K frames of CPU copies over gloo; not a measurement", "repeats": len(wins),
+              "timed_ms_total": round(sum(wins) * 1e3, 3),
+              "batch_ms": {"median": round(elapsed * 1e3, 5), "min": round(min(wins) * 1e3, 5), "max": round(max(wins) * 1e3, 5)}}
+    code = 2
+    if not args.no_verify:
+        if rank == pipe.root_of(last_frame):
+            m = _frame_matches_golden(pipe.frame(last_frame).numpy(), config, args.mode)
+            code = 2 if m is None else int(bool(m))
+    flag = torch.tensor([code], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    verified = {0: False, 1: True}.get(int(flag.item()))
+    return {"config": config, "elapsed": elapsed, "timing": timing, "verified": verified, "kernel_ms": None, "kernel": "oracle (dry run)",
+            "exchange_note": exchange_note, "rows": rows, "S_written": 4 if compact else S,
+            "W": W, "H": H, "ns": ns, "npl": npl, "seed": seed}
+
+
+def sharded_record(args, r, n_gpus, K, Wm):
+    """The line (or sub-record) of one configuration from run_sharded's result."""
+    W, H, ns, npl = r["W"], r["H"], r["ns"], r["npl"]
+    rays_per_frame = (W - 1) * H
+    mrays = rays_per_frame * K / r["elapsed"] / 1e6
+    g = golden().get("%s_%s" % (r["config"], args.mode), {})
+    hit_frac = (g.get("foreground_pixels") or 0) / float(rays_per_frame)
+    roofline = None
+    if r["kernel_ms"]:
+        # rank 0's slab launch: the trace kernel of a rank writes S bytes per pixel, or 4 when the slabs travel as pixel words
+        roofline = roofline_object(r["config"], args.mode, r["kernel"], W, H, r["S_written"], ns, npl, r["rows"], r["kernel_ms"], hit_frac)
+        roofline["kernel_ms_note"] = "rank 0's slab launch (%d rows) alone on one stream, HIP events" % r["rows"]
+    return {
+        "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": n_gpus, "steps": K, "warmup": Wm,
+        "ms_per_step": round(r["elapsed"] / K * 1e3, 5),
+        "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d"
+                               % (r["config"], W, H, ns, npl, args.mode, r["seed"]),
+                   "rays_per_frame": rays_per_frame, "kernel": r["kernel"], "prewarm_ms": args.prewarm_ms,
+                   "rows_per_rank": r["rows"],
+                   "parallelism": "rows sharded over %d GPUs; %s" % (n_gpus, r["exchange_note"])},
+        "timing": r["timing"], "roofline": roofline, "verified_against_golden": r["verified"],
+    }
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    force_dist = os.environ.get("RTX_BENCH_FORCE_DIST") == "1"
+    if (args.gpus > 1 or force_dist) and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher (a parent that never touches the GPU)
+        return self_launch(args, argv)
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_gpus = args.gpus
+    # RTX_BENCH_FORCE_DIST=1 with one rank walks the N>1 code (RCCL init, rings, all-reduce of the time) on a one-GPU
+    # box; the numbers it prints are not a bench line
+    distributed = world > 1 or force_dist
+    if distributed and world != n_gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (n_gpus, world))
+    if args.dry and not distributed:
+        raise SystemExit("--dry is the N>1 loop over gloo: use --gpus 2 or more")
+    if not args.dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the ray-trace path has no CPU fallback")
+    if distributed and args.what != "trace":
+        raise SystemExit("--what %s is N=1 only" % args.what)
+
+    R = importlib.import_module(PKG)
+    K, Wm = args.steps, args.warmup
+    if not distributed:
+        torch.cuda.set_device(0)
+        out = run_single(args, torch, R)
         print(json.dumps(out))
+        return 0
+
+    import torch.distributed as dist
+    sharding = importlib.import_module(PKG + ".sharding")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.dry:
+        dist.init_process_group(backend="gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    subs = args.sub_configs
+    if subs is None:
+        subs = "C4" if (args.config == "C2" and not args.dry and args.exchange != "p2p") else ""
+    subs = [s for s in subs.split(",") if s and s.lower() != "none"]
+    for s in subs:
+        if s not in R.CONFIGS:
+            raise SystemExit("--sub-configs: unknown config %r" % s)
+    results = []
+    for i, cfg in enumerate([args.config] + subs):
+        if args.dry:
+            results.append(run_sharded_dry(args, torch, dist, R, sharding, rank, world, cfg, K, Wm))
+        else:
+            W, H = R.CONFIGS[cfg][0], R.CONFIGS[cfg][1]
+            # the run-in that brings an idle GPU to its clocks: --prewarm-ms of frames at ~25 us per 1080p frame on one GPU;
+            # sub-records run on a warm GPU and take a tenth of it
+            frames = int(args.prewarm_ms * 40 * (1920.0 * 1080.0) / (W * H)) if i == 0 else int(args.prewarm_ms * 4 * (1920.0 * 1080.0) / (W * H))
+            results.append(run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, cfg, K, Wm, max(0, frames)))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank != 0:
+        return 0
+    main_rec = sharded_record(args, results[0], n_gpus, K, Wm)
+    out = {"metric": BASELINE_METRIC}
+    out.update(main_rec)
+    out.update({"higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic"})
+    if args.dry:
+        out["dry"] = True
+        out["data"] = "synthetic (dry run: CPU oracle as the renderer over gloo; not a measurement)"
+    # the CPU baseline of the main workload: rank 0, now that the ranks are done (it must not sit inside anyone's timed region)
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_leg(args.config, R.MODE_NAMES.index(args.mode), args.cpu_threads)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)
+    out["cpu_baseline"] = cpu
+    if subs:
+        out["configs"] = {}
+        for r in results[1:]:
+            rec = sharded_record(args, r, n_gpus, K, Wm)
+            rec["metric"] = "Mrays/s (primary rays), same loop, BASELINE config %s" % r["config"]
+            out["configs"][r["config"]] = rec
+    # key order of the contract first (readability only)
+    print(json.dumps(out))
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -289,9 +289,13 @@ class Context:
         self._check(lib().rtx_submit_frames(self._h, n, pa, mode, oa, sa))
 
     def make_submitter(self, params, mode, d_outs, streams):
-        """Pre-built argument arrays for repeatedly queueing the same batch (bench.py): returns a callable."""
+        """Pre-built argument arrays for repeatedly queueing the same batch (bench.py): returns a callable.
+        `params`: one rtx_params for every ring position, or a list with one per position (a camera per frame)."""
         n = len(d_outs)
-        pa = (Params * n)(*([params] * n))
+        plist = list(params) if isinstance(params, (list, tuple)) else [params] * n
+        if len(plist) != n:
+            raise ValueError("make_submitter: %d params for %d ring positions" % (len(plist), n))
+        pa = (Params * n)(*plist)
         oa = (_P * n)(*d_outs)
         sa = (_P * n)(*streams)
         fn, h = lib().rtx_submit_frames, self._h

@@ -31,3 +31,44 @@ def test_golden_frames_carry_the_hash_the_bench_checks():
         g = json.load(f)
     for key in ("C1_RGB_ASCII", "C2_RGB_ASCII", "C2_BIT_ASCII", "C3_RGB_ASCII", "C4_RGB_ASCII", "C5_RGB_ASCII"):
         assert len(g[key]["frame_sha256"]) == 64
+
+
+def test_committed_counters_are_dropped_when_the_sources_changed(tmp_path):
+    """roofline.traffic / roofline.valu come from profiles/counters.json only while the library sources still hash to
+    what was profiled: a kernel edit that keeps the kernel's name must not report stale counters."""
+    b = _bench()
+    root = tmp_path
+    (root / b.PKG / "csrc").mkdir(parents=True)
+    (root / "include").mkdir()
+    (root / "profiles").mkdir()
+    (root / b.PKG / "csrc" / "k.hip").write_text("__global__ void k() {}\n")
+    (root / "include" / "rtx.h").write_text("/* abi */\n")
+    h = b.csrc_sha256(str(root))
+    entry = {"csrc_sha256": h, "SQ_INSTS_VALU": 10.0, "total_bytes": 5.0}
+    (root / "profiles" / "counters.json").write_text(json.dumps({"C2_RGB_ASCII_k": entry, "C2_RGB_ASCII_old": {"SQ_INSTS_VALU": 1.0}}))
+    got, why = b.committed_counters("C2", "RGB_ASCII", "k", str(root))
+    assert got == entry and why is None
+    got, why = b.committed_counters("C2", "RGB_ASCII", "old", str(root))      # an entry from before the hash existed
+    assert got is None and "no source hash" in why
+    got, why = b.committed_counters("C2", "RGB_ASCII", "absent", str(root))
+    assert got is None and why
+    (root / b.PKG / "csrc" / "k.hip").write_text("__global__ void k() { /* edited */ }\n")
+    got, why = b.committed_counters("C2", "RGB_ASCII", "k", str(root))
+    assert got is None and "other sources" in why
+    r = b.roofline_object("C2", "RGB_ASCII", "k", 1920, 1080, 20, 1024, 1, 1080, 0.025, 0.5)
+    assert r["bytes_per_launch"] == 41479204 and abs(r["achieved"] - 41479204 / 25e-6 / 1e9) < 0.1
+
+
+def test_moving_view_ring_steps_by_a_constant_angle():
+    b = _bench()
+
+    class FakeR:
+        @staticmethod
+        def camera_params(w, h, pos=None, rot=None):
+            return rot[1]
+    import math
+    ys = b.moving_cameras(FakeR, 1920, 1080)
+    assert len(ys) == 1000
+    for i in range(1000):
+        assert abs(abs(ys[(i + 1) % 1000] - ys[i]) - b.MOVING_STEP_RAD) < 1e-9     # also across the wrap-around
+    assert abs(max(ys) - math.pi - 0.25) < 1e-9 and abs(min(ys) - math.pi + 0.25) < 1e-9

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Walks bench.py's N>1 code on a one-GPU box (world_size 1 over RCCL): tools/force_dist_gpu.sh [bench args]
+# Walks bench.py's N>1 code on a one-GPU box (world_size 1 over RCCL), through bench.py's own launcher (it starts its rank as a
+# child process, as `python bench.py --gpus N` does): tools/force_dist_gpu.sh [bench args]
 # The numbers are not a bench line (no peer: the all-to-all is a self-copy, and the one GPU traces, copies and expands
 # every frame); every run checks the last assembled frame against the golden hash and runs the check rounds.
 export RTX_BENCH_FORCE_DIST=1
 run() { printf "%-52s " "$*"
-  timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 \
-    bench.py --gpus 1 --steps 2000 --warmup 100 --no-cpu-baseline "$@" 2>gpurun_out/force_dist.err | tail -1 | python3 tools/fmt_bench_line.py || tail -3 gpurun_out/force_dist.err; }
+  timeout -k 10 300 python bench.py --gpus 1 --steps 2000 --warmup 100 --no-cpu-baseline --sub-configs none "$@" 2>gpurun_out/force_dist.err | tail -1 | python3 tools/fmt_bench_line.py || tail -3 gpurun_out/force_dist.err; }
 run --exchange compact "$@"
 run --exchange compact --graphs 0 "$@"
 run --exchange compact --latency "$@"

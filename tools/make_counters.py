@@ -24,11 +24,11 @@ def main():
         raise SystemExit("kernel match %r is not unique: %r" % (match, names))
     k = summ["kernels"][names[0]]
     c = k["counters_per_launch"]
-    entry = {"rocprof_kernel": names[0], "launches": k.get("launches"), "avg_us": k.get("avg_us"), "median_us": k.get("median_us"),
+    entry = {"rocprof_kernel": names[0], "csrc_sha256": summ.get("csrc_sha256"), "launches": k.get("launches"), "avg_us": k.get("avg_us"), "median_us": k.get("median_us"),
              "source": "%s (rocprofv3 --pmc, one counter group per pass; FETCH_SIZE doubled per MI355X_MICROARCH.md)"
                        % os.path.relpath(os.path.abspath(summary_path), root)}
     for name in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY",
-                 "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+                 "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"):
         if name in c:
             entry[name] = c[name]
     if "WRITE_SIZE" in c and "FETCH_SIZE" in c:

@@ -12,6 +12,10 @@ from collections import defaultdict
 def main():
     root = sys.argv[1]
     out = {"kernels": {}}
+    # what was profiled: the hash of the library sources in this snapshot (bench.py uses the counters only while it still holds)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["csrc_sha256"] = bench.csrc_sha256()
     # kernel trace
     for path in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         dur = defaultdict(list)

@@ -612,6 +612,10 @@ def run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, config,
         fixed_root = args.root == "fixed"      # in-order delivery: every frame assembled on rank 0, in frame order
         roots = [0] if fixed_root else None
         M = 1 if not compact else (args.frames_per_root or ({2: 8, 4: 8, 8: 8} if fixed_root else {2: 8, 4: 4, 8: 4}).get(world, max(1, 16 // world)))
+        # at most 512 MB per destination and round: a single transfer past 1 GiB arrived truncated in the world-size-1 walk of
+        # config 4 (16 units of 133 MB to one destination: frames 8..15 of every full round were stale), and rounds that large
+        # buy nothing anyway
+        M = max(1, min(M, (1 << 29) // max(1, 4 * W * max(1, rows))))
         post = torch.cuda.Stream()
         expanders = {}
         use_graphs = [compact and args.graphs != 0]

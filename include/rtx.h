@@ -93,9 +93,27 @@ enum rtx_option {
                                * grid, then every 64th (one 1080p launch alone: 29.3 -> 25.9 us).  Off for larger grids, where
                                * ordering gains nothing and at 8K costs 10 % by separating tiles that share 128-byte lines.
                                * 0 = frame order; k > 0 = on for every grid, the order re-derived every k-th frame */
+    RTX_OPT_CELL_REUSE = 8,   /* coarse-cell lists of that pre-pass outlive the frame: binned with every sphere's culling margin grown by a
+                               * motion budget (about eight frames of the camera's and the spheres' current motion), the lists serve
+                               * every later frame whose camera stays within it -- for a static view: all of them -- and are rebuilt
+                               * ahead of time, beside the frames, on the library's side stream.  A camera too fast for that (a
+                               * quarter of a cell per eight frames) gets the per-frame pre-pass.  Same frames either way: a list is
+                               * always a superset of what a pixel ray of its cell can hit.  -1 auto (on), 0 off, 1 on */
+    RTX_OPT_XCD_ORDER = 9,    /* two-level grids: dispatch the macro tiles so that a cell's tiles (and neighbouring cells) run on one
+                               * XCD, whose L2 then holds that part of the scene alone.  Speed only.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
                                * stays off) */
+};
+
+/* Read-only counters (rtx_get_option): how the coarse-cell lists of two-level culling were obtained so far. */
+enum rtx_stat {
+    RTX_STAT_CELL_BUILDS = 101,     /* binned in line because no cached list covered the camera */
+    RTX_STAT_CELL_PREFETCHES = 102, /* binned ahead of time on the side stream */
+    RTX_STAT_CELL_HITS = 103,       /* launches served by cached lists */
+    RTX_STAT_CELL_PER_FRAME = 104,  /* launches that binned for themselves alone (reuse off, or a fast camera) */
+    RTX_STAT_ORDER_PASSES = 105,    /* dispatch-order passes queued (rtx_balance_tiles / rtx_order_tiles) */
+    RTX_STAT_ORDERS_FROZEN = 106    /* dispatch orders a recorded launch reads (kept as they are from then on) */
 };
 
 /* Flags of rtx_render_rows. */
@@ -202,9 +220,15 @@ int rtx_expand(rtx_ctx* ctx, int mode, const void* d_compact, void* d_out, const
  * launch.  rtx_graph_begin puts `stream` (a hipStream_t) into capture; the rtx_submit_slabs / rtx_submit_frames /
  * rtx_render_rows / rtx_expand calls that follow on it (rtx_submit_slabs may fork to its other streams and joins them
  * back) are recorded instead of executed; rtx_graph_end ends the capture and returns an executable graph;
- * rtx_graph_launch replays it on a stream.  Recorded launches keep their arguments (camera, buffers, row range).
+ * rtx_graph_launch replays it on a stream.  Recorded launches keep their arguments (camera, buffers, row range) and
+ * the scene arrays' addresses and object counts: a graph belongs to the scene it was recorded on, and after
+ * rtx_scene_add_* / rtx_scene_clear rtx_graph_launch refuses it with RTX_ERR_INVALID_ARGUMENT ("re-capture after a scene
+ * edit"; rtx_update_objects moves spheres in place and is fine).  Recorded launches need caller buffers (not the
+ * context's own frame, whose zero-fill depends on what earlier launches left in it).  Dispatch order: nothing is derived
+ * while recording; a recorded launch runs under the order its tile grid has converged to on that stream, if any -- that
+ * order is then frozen for good -- and in frame order otherwise.
  * Not recordable, and reported as RTX_ERR_INVALID_ARGUMENT: a launch that needs a scene upload (render once before
- * capturing), the two-level pre-pass or the tile-order refresh (both alternate buffers from launch to launch).
+ * capturing) or the two-level pre-pass (its lists change from launch to launch).
  * No reference counterpart (one launch per frame on the default stream, RayTracingManager.cu:127-134). */
 int rtx_graph_begin(rtx_ctx* ctx, void* stream);
 int rtx_graph_end(rtx_ctx* ctx, void* stream, void** graph_out);

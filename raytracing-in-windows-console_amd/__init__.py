@@ -24,7 +24,8 @@ SIZE_8BIT, SIZE_RGB = 12, 20
 
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_TOO_LARGE = range(7)
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
-OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY = 1, 2, 3, 4, 5, 6, 7
+OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER = 1, 2, 3, 4, 5, 6, 7, 8, 9
+STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN = 101, 102, 103, 104, 105, 106
 RENDER_ZERO_TAIL = 1
 RENDER_COMPACT = 2
 RENDER_VALUES = 4
@@ -365,6 +366,9 @@ class Context:
         g = _P()
         self._check(lib().rtx_graph_end(self._h, stream, C.byref(g)))
         return g
+
+    def graph_launch(self, graph, stream=None):
+        self._check(lib().rtx_graph_launch(self._h, graph, stream))
 
     def graph_launcher(self, graph, stream=None):
         """A callable that replays `graph` on `stream` (pre-bound: one foreign call per replay)."""

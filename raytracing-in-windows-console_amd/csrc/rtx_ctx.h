@@ -3,6 +3,7 @@
 
 #include "../../include/rtx.h"
 #include "rtx_kernels.h"
+#include "rtx_plan.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -58,27 +59,51 @@ struct rtx_ctx {
     };
     std::vector<CellScratch> cell_scratch;
 
-    // heaviest-first dispatch order of the macro tiles, one set per render stream (everything that touches a set
-    // is queued on that one stream, in order: trace writes the estimates, rtx_order_tiles turns them into the
-    // order the following traces read).  `key` identifies the tile grid the buffers describe.
+    // dispatch order of the macro tiles, one set per (render stream, tile grid): everything that touches a set is queued
+    // on that one stream, in order (trace writes the estimates, rtx_order_tiles turns them into the order the following
+    // traces read) or on the context's side stream behind events (rtx_balance_tiles).  The decisions are
+    // rtxplan::DispatchOrder's; this holds the buffers and events.
     struct TileOrder {
         hipStream_t stream = nullptr;
+        uint64_t key[3] = {0, 0, 0}; // identifies the tile grid the buffers describe
         uint32_t* cost = nullptr;
-        uint32_t* order = nullptr;   // two orders of `cap` tiles: the one in use (cur) and the one a balancing pass writes
+        uint32_t* order = nullptr;   // two orders of `cap` tiles: the one in use and the one a balancing pass writes
         float* factor = nullptr;     // per-tile correction of the estimate (rtx_balance_tiles)
-        bool have_factor = false;
-        float last_view[12] = {0}, order_view[12] = {0}, pending_view[12] = {0}; // rotation + position: of the last launch, of the
-                                     // launch the order in use was measured on, of the launch the pass in flight reads
-        double last_drift = 0.0, order_drift = 0.0, pending_drift = 0.0; // ctx->scene_drift at the same three launches
-        int cur = 0;
-        int pending = 0;             // 0 = none; 1 = a balancing pass was queued after the last launch; 2 = ... before the last launch
         hipEvent_t ev_rec = nullptr, ev_done = nullptr;
         size_t cap = 0;              // tiles the buffers hold
-        uint64_t key[3] = {0, 0, 0};
-        bool have_order = false;
-        uint64_t frames = 0;         // traces of this grid since the last reset
+        uint64_t last_use = 0;       // ctx->order_clock at the last launch (least recently used set is recycled)
+        bool frozen = false;         // a recorded (HIP graph) launch reads the order in use: nothing is derived for this set any more
+        rtxplan::DispatchOrder plan;
     };
     std::vector<TileOrder> tile_orders;
+    uint64_t order_clock = 0;
+
+    // Coarse-cell lists that outlive a frame (two-level culling): two sets, shared by all render streams, each valid for
+    // cameras within the motion budget it was binned with (rtxplan::CellCachePolicy).  A set is (re)built on the render
+    // stream that missed, or ahead of time on the side stream; readers on other streams wait for `ev_built` once.
+    struct CellCacheSlot {
+        uint32_t* list = nullptr;
+        uint32_t* count = nullptr;
+        size_t list_words = 0, count_words = 0;
+        hipEvent_t ev_built = nullptr;
+        bool ever_built = false;
+        bool built_on_aux = false;              // the last build ran on the side stream
+        std::vector<hipStream_t> waited;        // streams that are already ordered after the last build
+        std::vector<hipStream_t> readers;       // streams that have queued launches reading this set since the last build
+        std::vector<hipEvent_t> reader_events;  // pool: one per reader, for ordering a rebuild after them
+    };
+    CellCacheSlot cell_cache[2];
+    rtxplan::CellCachePolicy cell_policy;
+    uint32_t* xcd_order = nullptr;              // static dispatch order of a two-level grid: a cell's tiles share an XCD
+    size_t xcd_order_cap = 0;
+    uint64_t xcd_order_key[2] = {0, 0};
+    int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
+    int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
+    uint64_t scene_gen = 1;                     // bumped by every scene edit (and by the first physics step after one)
+    bool physics_settled = false;               // every sphere has been through Sphere::Update since the last edit (|y| <= 10)
+    uint64_t stat_order_passes = 0;
+    uint64_t stat_cell_builds = 0, stat_cell_prefetches = 0, stat_cell_hits = 0, stat_cell_per_frame = 0;
+
     hipStream_t aux_stream = nullptr; // the balancing passes' stream (created with the first pass)
     double scene_drift = 0.0;        // how far any sphere can have moved since the context was created (rtx_update_objects:
                                      // |dt| x the largest speed; scene edits add 1e3): dispatch orders go stale with it
@@ -121,6 +146,7 @@ struct rtx_ctx {
 int rtx_fail(rtx_ctx* ctx, int status, const std::string& msg);
 int rtx_hip_fail(rtx_ctx* ctx, hipError_t e, const char* what);
 int rtx_sync_scene(rtx_ctx* ctx);
+void rtx_scene_edited(rtx_ctx* ctx);
 
 #define RTX_HIP(ctx, call)                          \
     do {                                            \

@@ -48,6 +48,10 @@ struct KArgs {
     uint32_t cell_log2gx, cell_log2gy; // a cell is 2^gx x 2^gy macro tiles
     uint32_t cells_x, cells_y;
     uint32_t cell_cap;        // entries per cell list
+    // rtx_bin_cells only: the motion budget the lists are built with (rtx_plan.hpp, "cell-list reuse"): they stay valid for
+    // cameras whose ray directions differ by at most bin_theta (chord of unit vectors) and whose position -- sphere
+    // motion counted in -- by at most bin_delta from this launch's.  0, 0: this camera only.
+    float bin_theta, bin_delta;
     // Heaviest-first dispatch (speed only; any permutation of the macro tiles renders the same frame): tile_order[b] =
     // bx | by << 16 of the macro tile that workgroup b (linear block index, x fastest) renders, built by
     // rtx_order_tiles / rtx_balance_tiles from tile_cost, the work estimate every workgroup of an earlier launch left

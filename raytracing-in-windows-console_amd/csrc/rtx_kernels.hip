@@ -110,6 +110,28 @@ __device__ __forceinline__ bool tile_culls(const TileFrustum& f, float ox, float
     return out;
 }
 
+// The same test with the margin grown for cell lists that are to outlive this frame (rtx_plan.hpp, "cell-list reuse"):
+// valid for every camera whose pixel directions are within theta (chord) of this one's and whose position, sphere motion
+// counted in, is within delta:   margin' = m + delta + theta (|O| + delta + m),   m = margin(r, |O| + delta),
+// times 1 + 4e-6 for the rounding of these few operations (hardware sqrt included).  `inside` reports whether some
+// such camera can lie inside or on the sphere (then it is never culled).  theta = delta = 0 gives tile_culls' margin
+// within that factor.
+__device__ __forceinline__ bool tile_culls_moving(const TileFrustum& f, float ox, float oy, float oz, float oo, float r, float theta, float delta, float& margin,
+                                                  bool& inside)
+{
+    const float dist = __builtin_amdgcn_sqrtf(oo) * (1.0f + 1.0e-6f) + delta; // >= |O| + delta
+    const float m = __builtin_amdgcn_sqrtf(r * r * (1.0f + kKappa) + kKappa * (dist * dist)) + kDelta * dist;
+    margin = (m + delta + theta * (dist + m)) * (1.0f + 4.0e-6f);
+    inside = !(__builtin_amdgcn_sqrtf(oo) * (1.0f - 1.0e-6f) - delta > fabsf(r) * (1.0f + 1.0e-6f));
+    bool out = false;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const float d = f.n[k].x * ox + f.n[k].y * oy + f.n[k].z * oz;
+        out = out || (d > margin);
+    }
+    return out;
+}
+
 // One plane of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows [row0, row0+h), grown by
 // half a pixel on every side, selected by k: 0..3 the side through corners k and k+1 (corner order (x0,y0) (x1,y0)
 // (x1,y1) (x0,y1)), 4 the axis plane -- arranged so that five lanes compute the five planes side by side.  Pixel
@@ -1148,10 +1170,12 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
             const float oo = ox * ox + oy * oy + oz * oz;
             const float cc = oo - (g[h].w * g[h].w);
             float mg;
-            const bool culled = tile_culls(fr, ox, oy, oz, oo, g[h].w, mg);
-            keep[h] = (k < hi) && !(cc > 0.0f && culled);
-            // camera inside or on the sphere: never culled, by any pyramid
-            rec[h] = make_float4(ox, oy, oz, cc > 0.0f ? mg : __builtin_inff());
+            bool inside;
+            const bool culled = tile_culls_moving(fr, ox, oy, oz, oo, g[h].w, a.bin_theta, a.bin_delta, mg, inside);
+            const bool outside = cc > 0.0f && !inside; // every camera the lists are for is strictly outside the sphere
+            keep[h] = (k < hi) && !(outside && culled);
+            // a camera inside or on the sphere: never culled, by any pyramid
+            rec[h] = make_float4(ox, oy, oz, outside ? mg : __builtin_inff());
         }
         const unsigned long long m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
         if (lane == 0) {

@@ -1,0 +1,624 @@
+// rtx_plan.hpp -- the host-side planning of a trace launch, as pure functions and small state machines.
+//
+// No HIP in here: everything rtx_render_rows decides before it queues anything -- the tile shape of a launch, the
+// coarse-cell grid of two-level culling, when a dispatch order is derived / used / stale, whether cached cell lists
+// still cover the current camera -- is computed from plain numbers, so that it compiles with any C++17 compiler and is
+// unit-tested on the CPU (tests/host/test_plan.cpp under -fsanitize=address,undefined).  rtx_api.cpp turns the
+// decisions into launches, events and buffers.
+//
+// Replaces the launch-shape arithmetic of RayTracingManager::Update (RayTracingManager.cu:120-134: a fixed 16x16 block
+// grid) and fills in the culling the reference only sketches in comments (RayTracingManager.cu:21-24, 109-117).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#ifndef RTX_WAVES_PER_EU
+#define RTX_WAVES_PER_EU 7 // waves per SIMD the trace kernels are compiled for (72 VGPRs)
+#endif
+
+namespace rtxplan {
+
+// A 256-thread workgroup puts one wave on each of a CU's four SIMDs, so a CU holds as many workgroups of the trace
+// kernels as a SIMD holds waves (their LDS, under 160 KB / 7, is sized to allow it).  The one place this number lives.
+constexpr uint32_t kResidentPerCU = RTX_WAVES_PER_EU;
+
+// ------------------------------------------------------------------------------------------------ views
+
+// The part of the frame parameters the per-tile work depends on: the rotation (upper 3x3 of inverseVMatrix, row-major)
+// and the camera position.
+struct View {
+    float rot[9] = {0};
+    float pos[3] = {0};
+};
+
+inline View view_of(const float inv_v[16], const float cam_pos[3])
+{
+    View v;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) v.rot[3 * r + c] = inv_v[4 * r + c];
+    }
+    for (int k = 0; k < 3; k++) v.pos[k] = cam_pos[k];
+    return v;
+}
+
+// How far two views are apart for the dispatch order's purposes: the largest change of a rotation entry (radians, for
+// small turns) or of a tenth of a position unit.  NaN counts as "as far as can be".
+inline float view_distance(const View& a, const View& b)
+{
+    float d = 0.0f;
+    for (int k = 0; k < 12; k++) {
+        const float x = k < 9 ? a.rot[k] : a.pos[k - 9], y = k < 9 ? b.rot[k] : b.pos[k - 9];
+        const float e = std::fabs(x - y) * (k < 9 ? 1.0f : 0.1f);
+        d = (e > d || e != e) ? e : d;
+    }
+    return d == d ? d : 1.0e30f;
+}
+
+// Extent of one pixel step on the view plane (tangent units): horizontally 2 e1 / W |M col 0|, vertically
+// 2 e2 / H |M col 1|.  Returns false (and 1, 1) for degenerate parameters.
+inline bool pixel_steps(const float inv_v[16], float e1, float e2, uint64_t W, uint64_t H, double* sx, double* sy)
+{
+    const float* m = inv_v;
+    const double cx = std::sqrt((double)m[0] * m[0] + (double)m[4] * m[4] + (double)m[8] * m[8]);
+    const double cy = std::sqrt((double)m[1] * m[1] + (double)m[5] * m[5] + (double)m[9] * m[9]);
+    *sx = 2.0 * std::fabs((double)e1) / (double)W * cx;
+    *sy = 2.0 * std::fabs((double)e2) / (double)H * cy;
+    if (!(*sx > 0.0) || !(*sy > 0.0) || !std::isfinite(*sx) || !std::isfinite(*sy)) {
+        *sx = *sy = 1.0;
+        return false;
+    }
+    return true;
+}
+
+// log2 of the width of the squarest (on the view plane) rectangle of `pixels` pixels, clamped to [lo, hi]:
+// minimise |log2((2^l * aspect) / (pixels / 2^l))|  ->  l = (log2(pixels) - log2(aspect)) / 2.
+inline uint32_t squarest_log2w(double aspect, int pixels, int lo, int hi)
+{
+    long l = std::lround(0.5 * (std::log2((double)pixels) - std::log2(aspect)));
+    if (l < lo) l = lo;
+    if (l > hi) l = hi;
+    return (uint32_t)l;
+}
+
+// ------------------------------------------------------------------------------------------------ tile shape
+
+struct TileRequest {
+    uint64_t W = 0, H = 0, rows = 0; // frame, and the rows this launch traces
+    uint32_t ns = 0;                 // spheres
+    double aspect = 1.0;             // horizontal / vertical extent of a pixel on the view plane
+    int n_cu = 0;
+    bool cull = false;               // the culling (binned) kernel family
+    int opt_subtiles = 0;            // RTX_OPT_SUBTILES (0 = choose)
+    int opt_tile_log2w = 0;          // RTX_OPT_TILE_LOG2_W (0 = choose)
+    int opt_refine = -1;             // RTX_OPT_REFINE (-1 auto)
+};
+
+struct TileShape {
+    uint32_t lw = 6, lnx = 0, nsub = 1; // sub-tile 2^lw x 2^(8-lw); macro tile 2^lnx sub-tiles wide, nsub >> lnx high
+    uint32_t mw = 64, mh = 4;           // macro tile, pixels
+    uint32_t grid_x = 1, grid_y = 1;    // workgroups
+    bool refine = false;                // per-wave refinement kernels (dense scenes)
+    uint64_t tiles256 = 0;              // 256-pixel tiles in the launch
+};
+
+constexpr double kDenseScene = 0.004; // spheres per pixel from which a scene counts as dense
+
+// Sub-tiles (256 pixels each) per workgroup, sub-tile shape and macro-tile layout: as square as possible on the view
+// plane, so that the culling pyramid is tight.  More sub-tiles amortise the per-workgroup set-up (tables, frustum,
+// staging) but leave fewer workgroups to fill the CUs and, with culling, lengthen the candidate lists.  Measured
+// (profiles/r01_d_subtiles.txt): brute kernel 1 / 4 / 8 at 400x150 / 1080p / 4K; binned kernel 4 at 1080p and 4K, 8 at
+// 8K, 2 for dense scenes.
+inline TileShape plan_tiles(const TileRequest& q)
+{
+    TileShape t;
+    t.tiles256 = (q.W * q.rows + 255u) / 256u;
+    const double density = (q.W && q.H) ? (double)q.ns / ((double)q.W * (double)q.H) : 0.0;
+    int nsub;
+    if (q.opt_subtiles) {
+        nsub = q.opt_subtiles;
+    } else if (q.cull) {
+        nsub = density >= kDenseScene ? 2 : (t.tiles256 >= 65536u ? 8 : 4);
+        // One dispatch round: up to 1080p (and for the row slabs of a sharded frame) take the smallest count that lets
+        // every workgroup be resident at once -- fewer, larger workgroups would leave CUs short of waves (a 135-row
+        // slab: 14.0 us with 4 sub-tiles, 9.5 with 1; 270 rows: 17.1 -> 11.9 with 2), more would need a second round;
+        // and with the tiles dealt so that every CU carries the same work one 1080p launch alone takes 25.4 instead of
+        // 29.7 us (profiles/r02_f_cu_balance.md, tools/slab_shapes_gpu.py).  1080p: 8100 tiles / 1792 slots -> 5.
+        if (nsub == 4 && q.n_cu > 0) {
+            const uint64_t slots = (uint64_t)kResidentPerCU * (uint64_t)q.n_cu;
+            const uint64_t one_round = (t.tiles256 + slots - 1) / slots;
+            if (one_round <= 6) nsub = (int)(one_round ? one_round : 1);
+        }
+    } else {
+        nsub = 1;
+        while (nsub < 8 && t.tiles256 >= (uint64_t)nsub * 4000u) nsub *= 2; // keep about 2000 workgroups or more
+    }
+    uint32_t lw;
+    if (q.opt_tile_log2w) {
+        lw = (uint32_t)q.opt_tile_log2w;
+    } else if (!q.cull) {
+        lw = 6u; // brute: 64x4, a wave writes one contiguous row span
+    } else {
+        lw = squarest_log2w(q.aspect, 256, 2, 6);
+    }
+    // macro tile of 256*nsub pixels, nx = 2^lnx sub-tiles wide and nsub/nx high, at most 128 x 128.  A sub-tile count
+    // that is not a power of two is stacked vertically (nx = 1).
+    uint32_t lnx = 0;
+    if ((nsub & (nsub - 1)) == 0) {
+        int lsub = 0;
+        while ((1 << lsub) < nsub) lsub++;
+        const uint32_t lmw = squarest_log2w(q.aspect, 256 * nsub, (int)lw, (int)lw + lsub);
+        lnx = lmw - lw;
+        while (lw + lnx > 7u) lnx--;                           // width  <= 128
+        while ((8u - lw) + ((uint32_t)lsub - lnx) > 7u) lnx++; // height <= 128
+    } else {
+        while ((256u >> lw) * (uint32_t)nsub > 128u && lw < 6u) lw++; // keep the stack within 128 rows
+    }
+    t.lw = lw;
+    t.lnx = lnx;
+    t.nsub = (uint32_t)nsub;
+    t.mw = (1u << lw) << lnx;
+    t.mh = ((256u >> lw) * (uint32_t)nsub) >> lnx;
+    t.grid_x = (uint32_t)((q.W + t.mw - 1) / t.mw);
+    t.grid_y = (uint32_t)((q.rows + t.mh - 1) / t.mh);
+    // dense scenes: every wave narrows the workgroup's candidate list to its own 64 pixels before scanning it
+    const bool want = q.opt_refine == 1 || (q.opt_refine < 0 && density >= kDenseScene);
+    t.refine = q.cull && want && nsub <= 4 && t.mw <= 64u && t.mh <= 64u; // (the REFINE kernels' tables: 64 x 64)
+    return t;
+}
+
+// Workgroups of the trace kernels the device holds at once.
+inline uint64_t resident_slots(int n_cu) { return (uint64_t)kResidentPerCU * (uint64_t)(n_cu > 0 ? n_cu : 0); }
+
+// ------------------------------------------------------------------------------------------------ coarse cells
+
+#ifndef RTX_CELLS_LARGE
+#define RTX_CELLS_LARGE 1024
+#endif
+#ifndef RTX_CELLS_SMALL
+#define RTX_CELLS_SMALL 256
+#endif
+#ifndef RTX_BIN_WGS
+#define RTX_BIN_WGS 1024
+#endif
+#ifndef RTX_BIN_MIN_ITEMS
+#define RTX_BIN_MIN_ITEMS 1024 // spheres a binning workgroup walks at least (two staging steps)
+#endif
+
+struct CellGrid {
+    uint32_t gx = 0, gy = 0;           // a cell is 2^gx x 2^gy macro tiles
+    uint32_t cells_x = 1, cells_y = 1, n_cells = 1, n_blocks = 1;
+    uint32_t cap = 1;                  // entries per cell list
+    uint32_t splits = 1;               // binning workgroups per block of 4 x 4 cells
+    uint32_t cell_w = 0, cell_h = 0;   // pixels
+};
+
+// Two-level culling for large scenes: coarse cells of 2^gx x 2^gy macro tiles -- about 256 of them, about 1024 from
+// 16384 spheres on, where shorter cell lists save the trace workgroups a staging step -- binned by ONE pre-pass launch
+// (rtx_bin_cells: blocks of 4 x 4 cells, then the cells of each block).
+inline CellGrid plan_cells(const TileShape& t, uint32_t ns, double aspect, int64_t opt_cell_capacity)
+{
+    CellGrid c;
+    const uint32_t tiles_x = t.grid_x, tiles_y = t.grid_y;
+    const uint64_t want_cells = ns >= 16384u ? (uint64_t)RTX_CELLS_LARGE : (uint64_t)RTX_CELLS_SMALL;
+    uint32_t gx = 0, gy = 0;
+    // grow the cell, keeping it square-ish on the view plane, until about want_cells cells remain
+    while ((uint64_t)((tiles_x + (1u << gx) - 1) >> gx) * ((tiles_y + (1u << gy) - 1) >> gy) > want_cells) {
+        const double wcell = (double)(t.mw << gx) * aspect, hcell = (double)(t.mh << gy);
+        if (wcell <= hcell && ((tiles_x + (1u << gx) - 1) >> gx) > 1u) gx++;
+        else if (((tiles_y + (1u << gy) - 1) >> gy) > 1u) gy++;
+        else gx++;
+    }
+    c.gx = gx;
+    c.gy = gy;
+    c.cells_x = (tiles_x + (1u << gx) - 1) >> gx;
+    c.cells_y = (tiles_y + (1u << gy) - 1) >> gy;
+    c.n_cells = c.cells_x * c.cells_y;
+    c.n_blocks = ((c.cells_x + 3u) >> 2) * ((c.cells_y + 3u) >> 2);
+    c.cell_w = t.mw << gx;
+    c.cell_h = t.mh << gy;
+    // Entries per cell list: four times the share of a uniform scene plus a floor, so that the scratch is O(spheres) --
+    // 4 ns + 1024 cells words -- instead of cells x ns.  A cell that needs more (a clustered scene) falls back to
+    // staging the whole scene: slower, never wrong.
+    uint32_t cap = opt_cell_capacity > 0 ? (uint32_t)opt_cell_capacity : (uint32_t)(4ull * ns / c.n_cells) + 1024u;
+    if (cap > ns) cap = ns; // a list never holds more than the scene
+    if (cap == 0) cap = 1;
+    c.cap = cap;
+    // the sphere array is split over several workgroups per block so that the pre-pass fills the chip: about 1024
+    // workgroups in all, each with at least RTX_BIN_MIN_ITEMS spheres
+    uint32_t splits = (uint32_t)RTX_BIN_WGS / c.n_blocks;
+    const uint32_t max_splits = (ns + (uint32_t)RTX_BIN_MIN_ITEMS - 1u) / (uint32_t)RTX_BIN_MIN_ITEMS;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1u) splits = 1u;
+    c.splits = splits;
+    return c;
+}
+
+// Static dispatch order of a two-level grid.  seq = the macro tiles cell by cell (cells row-major, a cell's tiles
+// row-major, tiles beyond the grid's edge skipped); dispatch position b takes seq[swz(b)], where swz is the bijective
+// XCD swizzle (cdna_hip_programming.md, "XCD swizzle must be bijective"): the blocks b, b + 8, b + 16, ... -- which share
+// an XCD under the round-robin placement observed on MI355X -- receive one contiguous run of seq.  order[b] = bx | by << 16.
+// Any permutation renders the same frame: the placement assumption costs speed if wrong, never a pixel.
+inline void xcd_cell_order(uint32_t grid_x, uint32_t grid_y, uint32_t gx, uint32_t gy, uint32_t* order)
+{
+    const uint32_t n = grid_x * grid_y, nxcd = 8u;
+    const uint32_t cw = 1u << gx, ch = 1u << gy;
+    const uint32_t cells_x = (grid_x + cw - 1u) >> gx, cells_y = (grid_y + ch - 1u) >> gy;
+    const uint32_t q = n / nxcd, r = n % nxcd;
+    // swz(b) -> position in seq; invert on the fly: walk seq and place each entry at the b with swz(b) = i
+    uint32_t i = 0;
+    for (uint32_t cy = 0; cy < cells_y; cy++) {
+        for (uint32_t cx = 0; cx < cells_x; cx++) {
+            for (uint32_t ty = cy * ch; ty < (cy + 1u) * ch && ty < grid_y; ty++) {
+                for (uint32_t tx = cx * cw; tx < (cx + 1u) * cw && tx < grid_x; tx++, i++) {
+                    // i = (xcd < r ? xcd (q+1) : r (q+1) + (xcd - r) q) + k,  b = k * 8 + xcd
+                    uint32_t xcd, k;
+                    if (i < r * (q + 1u)) {
+                        xcd = i / (q + 1u);
+                        k = i - xcd * (q + 1u);
+                    } else {
+                        const uint32_t j = i - r * (q + 1u);
+                        xcd = r + (q ? j / q : 0u);
+                        k = q ? j - (xcd - r) * q : 0u;
+                    }
+                    order[k * nxcd + xcd] = tx | (ty << 16);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch order
+
+// When a launch of a tile grid leaves work estimates, when a new dispatch order is derived from them, and which order
+// (if any) a launch runs under.  One per (stream, tile grid).  Any permutation renders the same frame: only speed
+// depends on this.
+//
+// Grids of one dispatch round (`one_round`): rtx_balance_tiles runs beside the frames on the library's side stream.
+// The launch a pass reads is followed by kLag - 1 launches that keep the old order and leave no estimates (the pass may
+// still be reading them); the launch after those waits for the pass -- by then long done -- and switches to the order it
+// wrote, in the other half of the order buffer.  An order is used only while the view is within kNear of the view it
+// was measured on (a stale heaviest-first order is a random order, which costs 3-5 % with frames in flight), refreshed
+// as soon as it is stale, and not derived at all while the camera moves faster than kNear per 16 frames.
+// Other grids: rtx_order_tiles is queued on the render stream itself, after the 1st and 2nd launch and then every
+// period-th.
+class DispatchOrder {
+public:
+    static constexpr int kLag = 3; // (at 2 the wait still stalls a 25 us frame: the pass starts 10 us after the launch it reads ends)
+    static constexpr float kNear = 0.004f; // radians (rotation entries) and tenths of a unit of camera position
+
+    struct Decision {
+        bool switch_order = false;   // before the launch: wait for the pending pass, then use the half it wrote
+        bool leave_estimates = false; // the launch stores its estimates and times (tile_cost != nullptr)
+        bool use_order = false;      // the launch reads the order in half `half`
+        int half = 0;
+        bool sort_now = false;       // after the launch: derive a new order from what it left
+        bool balance = false;        // ... with rtx_balance_tiles on the side stream (one-round grids), else rtx_order_tiles in line
+        bool prev_is_order = false;  // the launch ran under an order (the pass must map positions to tiles through it)
+        bool have_factor = false;    // the per-tile correction factors carry over
+    };
+
+    void reset()
+    {
+        have_order_ = have_factor_ = false;
+        frames_ = 0;
+        cur_ = 0;
+        pending_ = 0;
+    }
+    // A pass may still be queued when the grid changes: the caller waits for it, then calls reset().
+    bool pass_pending() const { return pending_ != 0; }
+    int current_half() const { return cur_; }
+    bool have_order() const { return have_order_; }
+    uint64_t frames() const { return frames_; }
+
+    // opt_tile_order: RTX_OPT_TILE_ORDER (-1 auto, k > 0 refresh period); drift: how far any sphere can have moved
+    // since the context was created (scene edits add 1e3).
+    Decision next(const View& v, double drift, bool one_round, int64_t opt_tile_order)
+    {
+        Decision d;
+        bool skip_estimates = false;
+        if (one_round) {
+            if (pending_ >= kLag) {
+                d.switch_order = true;
+                cur_ ^= 1;
+                have_order_ = true;
+                have_factor_ = true;
+                pending_ = 0;
+                order_view_ = pending_view_;
+                order_drift_ = pending_drift_;
+            } else if (pending_ >= 1) {
+                pending_++;
+                skip_estimates = true;
+            }
+        }
+        const uint64_t period = opt_tile_order > 0 ? (uint64_t)opt_tile_order : (one_round ? 64u : 16u);
+        d.use_order = have_order_;
+        if (one_round) {
+            // (spheres that rtx_update_objects moves count like a camera that moves: by the farthest any can have gone)
+            const float step = std::fmax(view_distance(v, last_view_), 0.1f * (float)(drift - last_drift_));
+            const float moved = std::fmax(view_distance(v, order_view_), 0.1f * (float)(drift - order_drift_));
+            last_view_ = v;
+            last_drift_ = drift;
+            const bool too_fast = step * 16.0f > kNear;
+            const bool stale = have_order_ && moved > kNear;
+            d.use_order = have_order_ && !stale;
+            // the corrections settle over a dozen passes: one every fourth launch at first, then every period-th, or as
+            // soon as the order has gone stale
+            d.sort_now = !skip_estimates && !too_fast && pending_ == 0 && (frames_ < 64 || (frames_ + 1) % period == 0 || stale);
+            if (d.sort_now) {
+                pending_view_ = v;
+                pending_drift_ = drift;
+            }
+            d.balance = true;
+        } else {
+            d.sort_now = frames_ < 2 || (frames_ + 1) % period == 0;
+        }
+        d.leave_estimates = d.sort_now; // estimates and times: only the launches a pass follows leave them
+        d.half = cur_;
+        d.prev_is_order = d.use_order;   // the pass maps dispatch positions to tiles through the order the launch really ran under
+        d.have_factor = have_factor_;    // (per tile, whatever order they were learnt under)
+        return d;
+    }
+
+    // After the launch (and the pass, if any) has been queued.
+    void launched(const Decision& d)
+    {
+        frames_++;
+        if (d.sort_now && d.balance) {
+            pending_ = 1;
+        } else if (d.sort_now) {
+            have_order_ = true; // rtx_order_tiles wrote the half in use, in stream order
+        }
+    }
+
+private:
+    View last_view_, order_view_, pending_view_; // of the last launch, of the launch the order in use was measured on, of the launch the pass in flight reads
+    double last_drift_ = 0.0, order_drift_ = 0.0, pending_drift_ = 0.0;
+    int cur_ = 0;
+    int pending_ = 0; // 0 = none; 1 = a pass was queued after the last launch; 2.. = launches since
+    bool have_order_ = false, have_factor_ = false;
+    uint64_t frames_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ cell-list reuse
+
+// Coarse-cell lists (rtx_bin_cells) stay valid while the camera and the scene have moved less than the margins the lists
+// were built with.  Soundness (one more term in DESIGN.md's "Culling soundness"): let the lists be built for camera
+// (o, M) with every sphere's culling margin grown to
+//     margin' = margin(r, |O| + delta) + delta + theta (|O| + delta + margin(r, |O| + delta)).
+// A ray of a later camera (o', M') for the same pixel has |o' - o| <= delta (sphere motion counted in) and a unit
+// direction d' with |d' - d| <= theta, where d (the old direction) satisfies n.d >= 0 for the five inward plane normals
+// of the cell's pyramid.  If the fp32 test reports a hit, the ray passes within R' <= margin(r, |O'|) of the centre c at a
+// point p = o' + t d' with -3u|O'| <= t <= |O'| + R'; then
+//     n.(c - o) = n.(c - p) + t n.d' + n.(o' - o) >= -R' - theta (|O'| + R') - 3u|O'| - delta >= -margin',
+// so the sphere is in the cell's list.  For rotations |d' - d| <= ||M' - M||_F + 2 eps when both matrices are orthonormal
+// to within eps (then |M p| = |p| (1 +- eps)); other matrices get no rotation budget (the lists are then reused only
+// for an identical matrix).
+struct CellCamera {
+    View view;
+    float e1 = 0, e2 = 0;
+    uint64_t W = 0, H = 0;
+    double drift = 0.0;       // ctx->scene_drift
+    uint64_t scene_gen = 0;   // bumped by every scene edit
+};
+
+struct CellKey { // the cell grid and everything its lists depend on besides the camera pose
+    uint64_t W = 0, H = 0, row0 = 0, rows = 0;
+    uint32_t lw = 0, lnx = 0, nsub = 0, gx = 0, gy = 0, cap = 0, ns = 0;
+    bool operator==(const CellKey& o) const
+    {
+        return W == o.W && H == o.H && row0 == o.row0 && rows == o.rows && lw == o.lw && lnx == o.lnx && nsub == o.nsub && gx == o.gx &&
+               gy == o.gy && cap == o.cap && ns == o.ns;
+    }
+};
+
+struct CellBudget {
+    float theta = 0.0f; // bound on |d' - d|
+    float delta = 0.0f; // bound on |o' - o| + sphere motion
+};
+
+// Largest singular value of a 3x3 matrix (row-major), from the largest eigenvalue of A^T A in closed form (trigonometric
+// solution of the symmetric 3x3 characteristic polynomial, in double), grown by 1e-6 relative + 1e-12: an upper bound on
+// |A v| for unit v.  (For the difference of two rotations this is 2 sin(phi/2); the Frobenius norm would say sqrt(2)
+// times that.)
+inline double spectral_norm3(const double a[9])
+{
+    double b[3][3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            b[i][j] = 0.0;
+            for (int k = 0; k < 3; k++) b[i][j] += a[3 * k + i] * a[3 * k + j];
+        }
+    }
+    const double p1 = b[0][1] * b[0][1] + b[0][2] * b[0][2] + b[1][2] * b[1][2];
+    const double tr = b[0][0] + b[1][1] + b[2][2];
+    double lmax;
+    if (!(tr == tr) || !(p1 == p1)) return 1.0e30;
+    if (p1 <= 1.0e-300) {
+        lmax = std::fmax(b[0][0], std::fmax(b[1][1], b[2][2]));
+    } else {
+        const double q = tr / 3.0;
+        const double p2 = (b[0][0] - q) * (b[0][0] - q) + (b[1][1] - q) * (b[1][1] - q) + (b[2][2] - q) * (b[2][2] - q) + 2.0 * p1;
+        const double pp = std::sqrt(p2 / 6.0);
+        double c[3][3];
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++) c[i][j] = (b[i][j] - (i == j ? q : 0.0)) / pp;
+        }
+        double r = 0.5 * (c[0][0] * (c[1][1] * c[2][2] - c[1][2] * c[2][1]) - c[0][1] * (c[1][0] * c[2][2] - c[1][2] * c[2][0]) +
+                          c[0][2] * (c[1][0] * c[2][1] - c[1][1] * c[2][0]));
+        r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+        lmax = q + 2.0 * pp * std::cos(std::acos(r) / 3.0);
+    }
+    // never below the largest column norm (a lower bound of the spectral norm that is exact to rounding): guards the
+    // closed form's cancellation for nearly singular A^T A
+    lmax = std::fmax(lmax, std::fmax(b[0][0], std::fmax(b[1][1], b[2][2])));
+    return std::sqrt(lmax > 0.0 ? lmax : 0.0) * (1.0 + 1.0e-6) + 1.0e-12;
+}
+
+// ||M^T M - I||_F of the upper 3x3: how far from orthonormal.
+inline float orthonormal_defect(const View& v)
+{
+    double s = 0.0;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            double g = 0.0;
+            for (int k = 0; k < 3; k++) g += (double)v.rot[3 * k + i] * (double)v.rot[3 * k + j];
+            g -= (i == j) ? 1.0 : 0.0;
+            s += g * g;
+        }
+    }
+    const double r = std::sqrt(s);
+    return r == r ? (float)r : 1.0e30f;
+}
+
+// What a camera `now` has used of the budgets of lists built for `built`: {bound on |d' - d|, bound on |o' - o| + drift}.
+// Infinite when anything else the lists depend on differs.
+inline CellBudget cell_motion(const CellCamera& built, const CellCamera& now)
+{
+    CellBudget m;
+    const float inf = 1.0e30f;
+    if (built.W != now.W || built.H != now.H || built.e1 != now.e1 || built.e2 != now.e2 || built.scene_gen != now.scene_gen ||
+        !(now.drift >= built.drift)) {
+        m.theta = m.delta = inf;
+        return m;
+    }
+    double p = 0.0, dm[9];
+    bool same_rot = true;
+    for (int k = 0; k < 9; k++) {
+        dm[k] = (double)now.view.rot[k] - (double)built.view.rot[k];
+        same_rot = same_rot && (now.view.rot[k] == built.view.rot[k]);
+    }
+    for (int k = 0; k < 3; k++) {
+        const double e = (double)now.view.pos[k] - (double)built.view.pos[k];
+        p += e * e;
+    }
+    if (same_rot) {
+        m.theta = 0.0f; // the very same matrix: the very same directions, orthonormal or not
+    } else {
+        const float eps = std::fmax(orthonormal_defect(built.view), orthonormal_defect(now.view));
+        m.theta = eps <= 1.0e-3f ? (float)(spectral_norm3(dm) * 1.0001 + 2.0 * eps + 1.0e-6) : inf;
+    }
+    const double dp = std::sqrt(p) * 1.0001 + (now.drift - built.drift);
+    m.delta = (dp == dp && dp < 1.0e30) ? (float)dp : inf;
+    if (m.delta > 0.0f) m.delta = m.delta * 1.0001f + 1.0e-30f;
+    if (!(m.theta == m.theta)) m.theta = inf;
+    return m;
+}
+
+// Two sets of lists (double-buffered) and the rule for using, prefetching and rebuilding them.
+class CellCachePolicy {
+public:
+    static constexpr float kFramesPerBuild = 8.0f; // a budget lasts about this many frames of the current motion
+    static constexpr float kCapFraction = 0.25f;   // ... but no more than this fraction of a cell's smaller angular extent
+
+    enum Action {
+        kUse = 0,       // the lists of slot `slot` cover this camera (slot may differ from the one used last: a finished prefetch)
+        kBuild = 1,     // none does: bin for this camera into slot `slot` with `budget`, in line, then use it
+        kPerFrame = 2   // the camera moves too fast for reuse to pay: bin per frame into the stream's own scratch, as without a cache
+    };
+    struct Decision {
+        Action action = kPerFrame;
+        int slot = 0;
+        CellBudget budget;        // kBuild: what to build with
+        bool prefetch = false;    // additionally: start building slot `prefetch_slot` for this camera on the side stream
+        int prefetch_slot = 0;
+        CellBudget prefetch_budget;
+    };
+
+    void invalidate()
+    {
+        slot_[0].valid = slot_[1].valid = false;
+        have_last_ = false;
+    }
+    bool slot_valid(int s) const { return slot_[s].valid; }
+    const CellBudget& slot_budget(int s) const { return slot_[s].budget; }
+
+    // cell_tan_w / cell_tan_h: a cell's extent on the view plane (tangent units); the cap on the rotation budget.
+    Decision decide(const CellKey& key, const CellCamera& cam, double cell_tan_w, double cell_tan_h)
+    {
+        Decision d;
+        // the step from the previous frame (whatever path that one took) sets the budgets of anything built now
+        // (after a scene edit or a change of the projection there is no step to speak of: budgets of zero, as for a first frame)
+        CellBudget step;
+        if (have_last_ && last_.W == cam.W && last_.H == cam.H && last_.e1 == cam.e1 && last_.e2 == cam.e2 && last_.scene_gen == cam.scene_gen &&
+            cam.drift >= last_.drift) {
+            step = cell_motion(last_, cam);
+        }
+        last_ = cam;
+        have_last_ = true;
+        const float theta_cap = (float)(kCapFraction * std::fmin(cell_tan_w, cell_tan_h));
+        CellBudget want;
+        want.theta = kFramesPerBuild * step.theta;
+        want.delta = kFramesPerBuild * step.delta;
+        const bool too_fast = !(want.theta <= theta_cap) || !(want.delta < 1.0e29f);
+
+        int best = -1;
+        float best_used = 2.0f;
+        for (int s = 0; s < 2; s++) {
+            if (!slot_[s].valid || !(slot_[s].key == key)) continue;
+            const CellBudget m = cell_motion(slot_[s].built_for, cam);
+            if (!(m.theta <= slot_[s].budget.theta) || !(m.delta <= slot_[s].budget.delta)) continue;
+            // fraction of the budget used: prefer the fresher lists
+            const float ut = slot_[s].budget.theta > 0.0f ? m.theta / slot_[s].budget.theta : 0.0f;
+            const float ud = slot_[s].budget.delta > 0.0f ? m.delta / slot_[s].budget.delta : 0.0f;
+            const float used = std::fmax(ut, ud);
+            if (used < best_used) {
+                best_used = used;
+                best = s;
+            }
+        }
+        if (best >= 0) {
+            d.action = kUse;
+            d.slot = best;
+            active_ = best;
+            // more than half used and the other slot does not already hold something fresher: rebuild there, beside the frames
+            const int other = best ^ 1;
+            if (best_used > 0.5f && !too_fast) {
+                bool other_fresher = false;
+                if (slot_[other].valid && slot_[other].key == key) {
+                    const CellBudget m = cell_motion(slot_[other].built_for, cam);
+                    other_fresher = m.theta <= 0.5f * slot_[other].budget.theta && m.delta <= 0.5f * slot_[other].budget.delta;
+                }
+                if (!other_fresher) {
+                    d.prefetch = true;
+                    d.prefetch_slot = other;
+                    d.prefetch_budget = want;
+                    slot_[other].valid = true;
+                    slot_[other].key = key;
+                    slot_[other].built_for = cam;
+                    slot_[other].budget = want;
+                }
+            }
+            return d;
+        }
+        if (too_fast) {
+            d.action = kPerFrame;
+            return d;
+        }
+        d.action = kBuild;
+        d.slot = active_ ^ 1; // the slot not used last: launches in flight may still read the other
+        if (!slot_[active_].valid) d.slot = active_;
+        d.budget = want;
+        slot_[d.slot].valid = true;
+        slot_[d.slot].key = key;
+        slot_[d.slot].built_for = cam;
+        slot_[d.slot].budget = want;
+        active_ = d.slot;
+        return d;
+    }
+
+private:
+    struct Slot {
+        bool valid = false;
+        CellKey key;
+        CellCamera built_for;
+        CellBudget budget;
+    };
+    Slot slot_[2];
+    int active_ = 0;
+    CellCamera last_;
+    bool have_last_ = false;
+};
+
+} // namespace rtxplan

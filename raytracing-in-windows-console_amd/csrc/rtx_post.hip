@@ -417,11 +417,26 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
     int rc = rtx_sync_scene(ctx);
     if (rc != RTX_OK) return rc;
     if (ctx->ns == 0) return RTX_OK;
+    // cell lists being built ahead of time on the side stream read the sphere positions: the step waits for them
+    for (auto& sl : ctx->cell_cache) {
+        if (sl.ever_built && sl.built_on_aux) RTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_built, 0));
+    }
     const unsigned blocks = (ctx->ns + rtx::kThreads - 1) / rtx::kThreads;
     hipLaunchKernelGGL(rtx::rtx_update_spheres, dim3(blocks), dim3(rtx::kThreads), 0, ctx->stream,
                        (float4*)ctx->d_sph_geom.p, (float4*)ctx->d_sph_motion.p, ctx->ns, dt);
     RTX_HIP(ctx, hipGetLastError());
-    ctx->scene_drift += std::fabs(dt) * (double)ctx->max_speed; // (dispatch orders age with the scene: rtx_render_rows)
+    // How far a sphere can have moved (dispatch orders age with it; cell lists are valid within it: rtx_plan.hpp).  A step
+    // moves a sphere by at most |speed dt| -- the clamp to [-10, 10] only shortens the move -- once it has been through one
+    // step; the FIRST step after an edit may pull a sphere from anywhere onto +-10 (Sphere.cu:18-22), so it counts as
+    // an edit.  A dt that is not a number moves spheres to NaN: an edit as well.
+    const double step = std::fabs(dt) * (double)ctx->max_speed;
+    if (!ctx->physics_settled || !(step == step) || !(step < 1.0e30)) {
+        rtx_scene_edited(ctx);
+        ctx->physics_settled = (step == step) && (step < 1.0e30);
+        ctx->scene_drift += 1.0e3;
+    } else {
+        ctx->scene_drift += step + 2.0e-6; // (+ the rounding of y to float: half an ulp of 10)
+    }
     return RTX_OK;
 }
 

@@ -1,0 +1,521 @@
+// Unit tests of csrc/rtx_plan.hpp -- the pure planning behind rtx_render_rows -- on the CPU:
+//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=all tests/host/test_plan.cpp -o test_plan && ./test_plan
+// (tests/test_host_plan.py builds and runs it).  No HIP, no GPU.
+#include "../../raytracing-in-windows-console_amd/csrc/rtx_plan.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+using namespace rtxplan;
+
+static int g_failed = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) {                                                           \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);          \
+            g_failed++;                                                          \
+        }                                                                        \
+    } while (0)
+
+// the reference camera at 1080p: yaw pi, element1 = 0.57735 * 1080 / 100, element2 = 0.57735
+static void yaw_matrix(double yaw, float m[16])
+{
+    const float c = (float)std::cos(yaw), s = (float)std::sin(yaw);
+    const float r[16] = {c, 0, s, 0, 0, 1, 0, 0, -s, 0, c, 0, 0, 0, 0, 1};
+    std::memcpy(m, r, sizeof r);
+}
+
+static TileRequest request(uint64_t W, uint64_t H, uint64_t rows, uint32_t ns, bool cull)
+{
+    float m[16];
+    yaw_matrix(3.14159265, m);
+    double sx, sy;
+    pixel_steps(m, 0.57735f * (float)H / 100.0f, 0.57735f, W, H, &sx, &sy);
+    TileRequest q;
+    q.W = W;
+    q.H = H;
+    q.rows = rows;
+    q.ns = ns;
+    q.aspect = sx / sy;
+    q.n_cu = 256;
+    q.cull = cull;
+    return q;
+}
+
+static void test_tile_shapes()
+{
+    // config 2: 8100 tiles of 256 pixels over 1792 resident slots -> 5 sub-tiles, one dispatch round
+    TileShape t = plan_tiles(request(1920, 1080, 1080, 1025, true));
+    CHECK(t.nsub == 5 && !t.refine);
+    CHECK((uint64_t)t.grid_x * t.grid_y <= resident_slots(256));
+    CHECK(t.mw <= 128 && t.mh <= 128 && t.mw * t.mh == 256u * t.nsub);
+    CHECK((uint64_t)t.grid_x * t.mw >= 1920 && (uint64_t)t.grid_y * t.mh >= 1080);
+    // config 5: dense -> 2 sub-tiles, per-wave refinement, macro tile within 64 x 64
+    t = plan_tiles(request(1920, 1080, 1080, 65536, true));
+    CHECK(t.nsub == 2 && t.refine && t.mw <= 64 && t.mh <= 64);
+    // config 4 (8K): 8 sub-tiles, several rounds
+    t = plan_tiles(request(7680, 4320, 4320, 1024, true));
+    CHECK(t.nsub == 8 && (uint64_t)t.grid_x * t.grid_y > resident_slots(256));
+    // the slabs of a sharded 1080p frame: the smallest count that keeps one round
+    CHECK(plan_tiles(request(1920, 1080, 540, 1025, true)).nsub == 3);
+    CHECK(plan_tiles(request(1920, 1080, 270, 1025, true)).nsub == 2);
+    CHECK(plan_tiles(request(1920, 1080, 135, 1025, true)).nsub == 1);
+    // brute: 64 x 4 sub-tiles
+    t = plan_tiles(request(400, 150, 150, 6, false));
+    CHECK(t.lw == 6 && t.nsub == 1 && t.mw == 64 && t.mh == 4);
+    // every shape the options can ask for stays within the kernel's limits
+    for (int sub : {1, 2, 3, 4, 5, 6, 8, 16}) {
+        for (int lw = 2; lw <= 6; lw++) {
+            TileRequest q = request(1000, 700, 700, 5000, true);
+            q.opt_subtiles = sub;
+            q.opt_tile_log2w = lw;
+            t = plan_tiles(q);
+            CHECK(t.nsub == (uint32_t)sub && t.mw * t.mh == 256u * t.nsub);
+            if ((sub & (sub - 1)) == 0) CHECK(t.mw <= 128 && t.mh <= 128);
+        }
+    }
+    // degenerate frames
+    t = plan_tiles(request(1, 1, 1, 100, true));
+    CHECK(t.grid_x == 1 && t.grid_y == 1);
+}
+
+static void test_cell_grid()
+{
+    const TileRequest q = request(1920, 1080, 1080, 65536, true);
+    const TileShape t = plan_tiles(q);
+    const CellGrid g = plan_cells(t, 65536, q.aspect, 0);
+    CHECK(g.n_cells == g.cells_x * g.cells_y && g.n_cells <= 1024 && g.n_cells >= 256);
+    CHECK(g.cap == 4u * 65536u / g.n_cells + 1024u);
+    CHECK((uint64_t)g.cells_x << g.gx >= t.grid_x && (uint64_t)g.cells_y << g.gy >= t.grid_y);
+    CHECK(g.splits >= 1 && g.splits * g.n_blocks <= 1024 + g.n_blocks);
+    CHECK(g.cell_w == t.mw << g.gx && g.cell_h == t.mh << g.gy);
+    // the scratch is O(spheres): 4 ns + 1024 cells words
+    CHECK((uint64_t)g.n_cells * g.cap <= 4ull * 65536 + 1024ull * g.n_cells);
+    // small scenes: the capacity never exceeds the scene; an explicit capacity is taken as is
+    const CellGrid s = plan_cells(t, 100, q.aspect, 0);
+    CHECK(s.cap == 100 && s.splits == 1);
+    CHECK(plan_cells(t, 65536, q.aspect, 7).cap == 7);
+}
+
+static void test_xcd_order()
+{
+    for (auto dims : std::vector<std::vector<uint32_t>>{{30, 135, 0, 2}, {64, 64, 1, 1}, {7, 9, 2, 1}, {120, 34, 2, 0}, {1, 64, 0, 0}, {100, 1, 3, 0}}) {
+        const uint32_t gx_n = dims[0], gy_n = dims[1], gx = dims[2], gy = dims[3], n = gx_n * gy_n;
+        std::vector<uint32_t> order(n, 0xffffffffu);
+        xcd_cell_order(gx_n, gy_n, gx, gy, order.data());
+        // a permutation of the tiles
+        std::vector<int> seen(n, 0);
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t bx = order[b] & 0xffffu, by = order[b] >> 16;
+            CHECK(bx < gx_n && by < gy_n);
+            if (bx < gx_n && by < gy_n) seen[by * gx_n + bx]++;
+        }
+        CHECK(std::all_of(seen.begin(), seen.end(), [](int c) { return c == 1; }));
+        // the blocks that share an XCD (equal b % 8) cover few cells: at most their share plus the two they cut
+        const uint32_t cells_x = (gx_n + (1u << gx) - 1) >> gx;
+        const uint32_t n_cells = cells_x * ((gy_n + (1u << gy) - 1) >> gy);
+        for (uint32_t x = 0; x < 8 && n >= 64; x++) {
+            std::vector<uint32_t> cells;
+            for (uint32_t b = x; b < n; b += 8) cells.push_back(((order[b] >> 16) >> gy) * cells_x + ((order[b] & 0xffffu) >> gx));
+            std::sort(cells.begin(), cells.end());
+            cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
+            if (!(cells.size() <= n_cells / 8 + n_cells / 64 + 2)) std::printf("grid %u x %u cells 2^%u x 2^%u: xcd %u touches %zu of %u cells\n", gx_n, gy_n, gx, gy, x, cells.size(), n_cells);
+            CHECK(cells.size() <= n_cells / 8 + n_cells / 64 + 2); // (cells cut by the grid's edge hold fewer tiles)
+            CHECK(cells.back() - cells.front() + 1 == cells.size()); // a contiguous run of cells
+        }
+    }
+}
+
+static View yaw_view(double yaw, float px = 0, float py = 0, float pz = 0)
+{
+    float m[16];
+    yaw_matrix(yaw, m);
+    const float pos[3] = {px, py, pz};
+    return view_of(m, pos);
+}
+
+static void test_dispatch_order_static_view()
+{
+    DispatchOrder o;
+    const View v = yaw_view(3.14159265);
+    int sorts = 0, switches = 0, since_sort = -1000;
+    bool used_before_switch = false;
+    for (int f = 0; f < 400; f++) {
+        const DispatchOrder::Decision d = o.next(v, 0.0, true, -1);
+        if (d.switch_order) {
+            switches++;
+            CHECK(since_sort >= DispatchOrder::kLag - 1); // the launches between a pass and the switch to its order
+        }
+        if (d.use_order && switches == 0) used_before_switch = true;
+        if (d.sort_now) {
+            CHECK(d.leave_estimates && d.balance);
+            CHECK(!o.pass_pending());                     // never two passes in flight
+            CHECK(d.prev_is_order == d.use_order);        // the pass is told the order the launch really ran under
+            sorts++;
+            since_sort = 0;
+        } else {
+            CHECK(!d.leave_estimates);
+            since_sort++;
+        }
+        if (d.use_order) CHECK(d.half == o.current_half());
+        o.launched(d);
+    }
+    CHECK(!used_before_switch);
+    CHECK(sorts >= 16 && sorts <= 40);   // one in three launches for the first 64, then every 64th
+    CHECK(switches == sorts || switches == sorts - 1);
+    CHECK(o.have_order());
+}
+
+static void test_dispatch_order_moving_views()
+{
+    // a camera that creeps: the order goes stale and is refreshed, and a stale order is never used
+    {
+        DispatchOrder o;
+        int stale_used = 0, sorts = 0;
+        double measured_at = 0.0, pending_at = 0.0;
+        for (int f = 0; f < 2000; f++) {
+            const double yaw = 3.14159265 + 1.0e-4 * f;
+            const DispatchOrder::Decision d = o.next(yaw_view(yaw), 0.0, true, -1);
+            if (d.switch_order) measured_at = pending_at;
+            if (d.use_order && std::fabs(yaw - measured_at) > 1.5 * DispatchOrder::kNear) stale_used++;
+            if (d.sort_now) {
+                sorts++;
+                pending_at = yaw;
+            }
+            o.launched(d);
+        }
+        CHECK(stale_used == 0);
+        CHECK(sorts > 20); // kept up with the camera
+    }
+    // a camera that jumps every frame: nothing is derived, nothing is used
+    {
+        DispatchOrder o;
+        int sorts = 0, used = 0;
+        for (int f = 0; f < 300; f++) {
+            const DispatchOrder::Decision d = o.next(yaw_view(3.14159265 + 0.01 * f), 0.0, true, -1);
+            // (the very first launch has no previous view to compare with other than the zero view: it may sort once)
+            sorts += d.sort_now && f > 0;
+            used += d.use_order;
+            o.launched(d);
+        }
+        CHECK(sorts == 0 && used == 0);
+    }
+    // spheres that move (scene drift) age an order like a camera that moves
+    {
+        DispatchOrder o;
+        const View v = yaw_view(3.14159265);
+        int used_late = 0;
+        for (int f = 0; f < 200; f++) {
+            const double drift = f < 100 ? 0.0 : 0.5 * (f - 99); // physics starts at frame 100: half a unit per frame
+            const DispatchOrder::Decision d = o.next(v, drift, true, -1);
+            if (f > 110 && d.use_order) used_late++;
+            o.launched(d);
+        }
+        CHECK(used_late == 0);
+    }
+    // grids of several rounds: in-line sort after the 1st and 2nd launch, then every 16th; the order is used from then on
+    {
+        DispatchOrder o;
+        std::vector<int> sorted_at;
+        for (int f = 0; f < 40; f++) {
+            const DispatchOrder::Decision d = o.next(yaw_view(3.14159265), 0.0, false, -1);
+            CHECK(!d.balance && !d.switch_order);
+            if (d.sort_now) sorted_at.push_back(f);
+            CHECK(d.use_order == (f >= 1));
+            o.launched(d);
+        }
+        CHECK((sorted_at == std::vector<int>{0, 1, 15, 31}));
+    }
+    // reset with a pass pending (the grid changed): starts over cleanly
+    {
+        DispatchOrder o;
+        DispatchOrder::Decision d = o.next(yaw_view(3.14159265), 0.0, true, -1); // (no view before it to compare with: no pass yet)
+        o.launched(d);
+        d = o.next(yaw_view(3.14159265), 0.0, true, -1);
+        CHECK(d.sort_now);
+        o.launched(d);
+        CHECK(o.pass_pending());
+        o.reset();
+        CHECK(!o.pass_pending() && !o.have_order() && o.frames() == 0);
+        d = o.next(yaw_view(3.14159265), 0.0, true, -1);
+        CHECK(!d.switch_order && !d.use_order && d.sort_now);
+        // spectral norm of a rotation difference: 2 sin(phi / 2), not sqrt(2) times it
+        const View va = yaw_view(1.0), vb = yaw_view(1.01);
+        double dm[9];
+        for (int k = 0; k < 9; k++) dm[k] = (double)vb.rot[k] - (double)va.rot[k];
+        const double sn = spectral_norm3(dm);
+        CHECK(sn >= 2.0 * std::sin(0.005) * 0.9999 && sn <= 2.0 * std::sin(0.005) * 1.0001 + 1e-6);
+        const double zero[9] = {0};
+        CHECK(spectral_norm3(zero) <= 1e-11);
+        const double diag[9] = {3, 0, 0, 0, -7, 0, 0, 0, 2};
+        CHECK(std::fabs(spectral_norm3(diag) - 7.0) < 1e-4);
+    }
+}
+
+// ---- cell-list reuse
+
+static CellCamera cell_camera(double yaw, float px, float py, float pz, double drift = 0.0, uint64_t gen = 1)
+{
+    CellCamera c;
+    c.view = yaw_view(yaw, px, py, pz);
+    c.e1 = 6.2354f;
+    c.e2 = 0.57735f;
+    c.W = 1920;
+    c.H = 1080;
+    c.drift = drift;
+    c.scene_gen = gen;
+    return c;
+}
+
+static void test_cell_motion_bounds_direction_change()
+{
+    std::mt19937 rng(7);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    for (int it = 0; it < 2000; it++) {
+        const double yaw0 = 3.0 * u(rng), dyaw = 0.05 * u(rng);
+        const CellCamera a = cell_camera(yaw0, 0, 0, 0), b = cell_camera(yaw0 + dyaw, (float)(0.3 * u(rng)), (float)(0.3 * u(rng)), (float)(0.3 * u(rng)));
+        const CellBudget m = cell_motion(a, b);
+        CHECK(m.theta < 1.0e29f && m.delta < 1.0e29f);
+        // the same pixel's unit direction under both matrices: |d' - d| <= theta
+        for (int k = 0; k < 8; k++) {
+            const double p[3] = {6.2354 * u(rng), 0.57735 * u(rng), 1.0};
+            double d0[3], d1[3], n0 = 0, n1 = 0;
+            for (int r = 0; r < 3; r++) {
+                d0[r] = a.view.rot[3 * r] * p[0] + a.view.rot[3 * r + 1] * p[1] + a.view.rot[3 * r + 2] * p[2];
+                d1[r] = b.view.rot[3 * r] * p[0] + b.view.rot[3 * r + 1] * p[1] + b.view.rot[3 * r + 2] * p[2];
+                n0 += d0[r] * d0[r];
+                n1 += d1[r] * d1[r];
+            }
+            double e = 0;
+            for (int r = 0; r < 3; r++) {
+                const double x = d1[r] / std::sqrt(n1) - d0[r] / std::sqrt(n0);
+                e += x * x;
+            }
+            CHECK(std::sqrt(e) <= m.theta);
+        }
+        const double dp = std::sqrt((double)b.view.pos[0] * b.view.pos[0] + (double)b.view.pos[1] * b.view.pos[1] + (double)b.view.pos[2] * b.view.pos[2]);
+        CHECK(m.delta >= (float)dp);
+    }
+    // identical cameras use nothing; anything else the lists depend on makes them unusable
+    const CellCamera a = cell_camera(3.14159265, 1, 2, 3, 5.0);
+    CellBudget m = cell_motion(a, a);
+    CHECK(m.theta == 0.0f && m.delta == 0.0f);
+    CellCamera b = a;
+    b.scene_gen = 2;
+    CHECK(cell_motion(a, b).theta > 1.0e29f);
+    b = a;
+    b.e1 = 6.0f;
+    CHECK(cell_motion(a, b).delta > 1.0e29f);
+    b = a;
+    b.drift = 4.0; // drift only grows
+    CHECK(cell_motion(a, b).delta > 1.0e29f);
+    b = a;
+    b.drift = 5.5;
+    CHECK(cell_motion(a, b).delta >= 0.5f && cell_motion(a, b).delta < 0.51f);
+    // a matrix that is not a rotation gets no rotation budget unless it is the very same matrix
+    CellCamera s = a;
+    for (float& x : s.view.rot) x *= 2.0f;
+    CHECK(cell_motion(s, s).theta == 0.0f);
+    CellCamera s2 = s;
+    s2.view.rot[0] += 1.0e-3f;
+    CHECK(cell_motion(s, s2).theta > 1.0e29f);
+    b = a;
+    b.view.rot[4] = std::nanf("");
+    CHECK(cell_motion(a, b).theta > 1.0e29f);
+}
+
+// The inequality behind the grown margin, checked numerically in double: a point within R of the centre on a ray of
+// the moved camera never lies further behind an old pyramid plane than margin' = R + delta + theta (|O'| + R).
+static void test_grown_margin_inequality()
+{
+    std::mt19937 rng(11);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    auto unit = [&](double v[3]) {
+        double n;
+        do {
+            for (int k = 0; k < 3; k++) v[k] = u(rng);
+            n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        } while (n < 0.1 || n > 1.0);
+        for (int k = 0; k < 3; k++) v[k] /= n;
+    };
+    for (int it = 0; it < 200000; it++) {
+        double n[3], d[3], w[3], w2[3], w3[3];
+        unit(n);
+        unit(d);
+        const double nd = n[0] * d[0] + n[1] * d[1] + n[2] * d[2];
+        if (nd < 0) {
+            for (int k = 0; k < 3; k++) d[k] = -d[k]; // the old ray lies on the inner side of the plane
+        }
+        const double theta = 0.05 * std::fabs(u(rng)), delta = 2.0 * std::fabs(u(rng)), R = 3.0 * std::fabs(u(rng));
+        // d': a unit vector within chord theta of d
+        unit(w);
+        double dp[3], len = 0;
+        const double sc = 0.999 * theta * std::fabs(u(rng));
+        for (int k = 0; k < 3; k++) dp[k] = d[k] + sc * w[k];
+        for (int k = 0; k < 3; k++) len += dp[k] * dp[k];
+        for (int k = 0; k < 3; k++) dp[k] /= std::sqrt(len);
+        double chord = 0;
+        for (int k = 0; k < 3; k++) chord += (dp[k] - d[k]) * (dp[k] - d[k]);
+        if (std::sqrt(chord) > theta) continue;
+        // o' within delta of o (= 0); p on the new ray; c within R of p
+        unit(w2);
+        unit(w3);
+        const double t = 200.0 * std::fabs(u(rng)), so = delta * std::fabs(u(rng)), sr = R * std::fabs(u(rng));
+        double o2[3], c[3];
+        for (int k = 0; k < 3; k++) {
+            o2[k] = so * w2[k];
+            c[k] = o2[k] + t * dp[k] + sr * w3[k];
+        }
+        double O2 = 0;
+        for (int k = 0; k < 3; k++) O2 += (o2[k] - c[k]) * (o2[k] - c[k]);
+        O2 = std::sqrt(O2);
+        const double lhs = n[0] * c[0] + n[1] * c[1] + n[2] * c[2]; // n . (c - o)
+        CHECK(lhs >= -(R + delta + theta * (O2 + R)) - 1e-9);
+    }
+}
+
+static void test_cell_cache_policy()
+{
+    CellKey key;
+    key.W = 1920;
+    key.H = 1080;
+    key.rows = 1080;
+    key.lw = 4;
+    key.nsub = 2;
+    key.ns = 65536;
+    key.cap = 1280;
+    const double cw = 0.4, ch = 0.035; // a cell's extent on the view plane (config 5)
+    auto covered = [&](const CellCachePolicy& pol, const std::vector<std::pair<CellCamera, CellBudget>>& built, int slot, const CellCamera& cam) {
+        (void)pol;
+        const CellBudget m = cell_motion(built[(size_t)slot].first, cam);
+        return m.theta <= built[(size_t)slot].second.theta && m.delta <= built[(size_t)slot].second.delta;
+    };
+    // static view: one build, then hits for ever; zero budgets (the lists are exact)
+    {
+        CellCachePolicy pol;
+        std::vector<std::pair<CellCamera, CellBudget>> built(2);
+        int builds = 0, hits = 0;
+        for (int f = 0; f < 100; f++) {
+            const CellCamera cam = cell_camera(3.14159265, 0, 0, 0);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            if (d.action == CellCachePolicy::kBuild) {
+                builds++;
+                CHECK(d.budget.theta == 0.0f && d.budget.delta == 0.0f);
+                built[(size_t)d.slot] = {cam, d.budget};
+            } else {
+                CHECK(d.action == CellCachePolicy::kUse && !d.prefetch);
+                hits++;
+            }
+        }
+        CHECK(builds == 1 && hits == 99);
+    }
+    // a camera that turns slowly and drifts: after the first frames every launch is served by lists that cover it (the
+    // decision is re-checked here against what the slots were built with), rebuilt ahead of time
+    for (double step : {1.0e-4, 5.0e-4, 1.0e-3}) {
+        CellCachePolicy pol;
+        std::vector<std::pair<CellCamera, CellBudget>> built(2);
+        int builds = 0, hits = 0, prefetches = 0, per_frame = 0;
+        for (int f = 0; f < 600; f++) {
+            const CellCamera cam = cell_camera(3.14159265 + step * f, (float)(0.01 * f), 0, 0, 0.002 * f);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            if (d.action == CellCachePolicy::kBuild) {
+                builds++;
+                built[(size_t)d.slot] = {cam, d.budget};
+            } else if (d.action == CellCachePolicy::kUse) {
+                hits++;
+                CHECK(covered(pol, built, d.slot, cam));
+            } else {
+                per_frame++;
+            }
+            if (d.prefetch) {
+                prefetches++;
+                CHECK(d.action == CellCachePolicy::kUse && d.prefetch_slot != d.slot);
+                built[(size_t)d.prefetch_slot] = {cam, d.prefetch_budget};
+            }
+        }
+        CHECK(per_frame == 0);
+        CHECK(builds <= 3);               // the start-up only (no step known yet; then the first real budget)
+        CHECK(hits >= 595 && prefetches >= 600 / 10 && prefetches <= 600 / 2);
+    }
+    // a camera too fast for a quarter of a cell per eight frames: per-frame binning, no cache traffic
+    {
+        CellCachePolicy pol;
+        int per_frame = 0;
+        for (int f = 0; f < 50; f++) {
+            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch);
+            per_frame += d.action == CellCachePolicy::kPerFrame;
+            CHECK(!d.prefetch);
+        }
+        CHECK(per_frame >= 48);
+    }
+    // ... and when it comes to rest the lists are built again
+    {
+        CellCachePolicy pol;
+        for (int f = 0; f < 20; f++) pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch);
+        int builds = 0, hits = 0;
+        for (int f = 0; f < 20; f++) {
+            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.2, 0, 0, 0), cw, ch);
+            builds += d.action == CellCachePolicy::kBuild;
+            hits += d.action == CellCachePolicy::kUse;
+        }
+        CHECK(builds == 1 && hits == 18);
+    }
+    // a scene edit, another grid, an explicit invalidate: never served from the old lists
+    {
+        CellCachePolicy pol;
+        const CellCamera cam = cell_camera(3.14159265, 0, 0, 0);
+        CHECK(pol.decide(key, cam, cw, ch).action == CellCachePolicy::kBuild);
+        CHECK(pol.decide(key, cam, cw, ch).action == CellCachePolicy::kUse);
+        CellCamera edited = cam;
+        edited.scene_gen = 2;
+        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kBuild); // (an edit is not a fast camera: rebuilt at once)
+        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kUse);
+        CellKey other = key;
+        other.rows = 540;
+        CHECK(pol.decide(other, edited, cw, ch).action == CellCachePolicy::kBuild);
+        CHECK(pol.decide(other, edited, cw, ch).action == CellCachePolicy::kUse);
+        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kUse);   // the first grid's lists are in the other slot still
+        pol.invalidate();
+        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kBuild);
+    }
+    // physics: spheres that move (drift) use the position budget like a moving camera
+    {
+        CellCachePolicy pol;
+        std::vector<std::pair<CellCamera, CellBudget>> built(2);
+        int misses = 0;
+        for (int f = 0; f < 300; f++) {
+            const CellCamera cam = cell_camera(3.14159265, 0, 0, 0, 0.06 * f);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            if (d.action == CellCachePolicy::kBuild) {
+                built[(size_t)d.slot] = {cam, d.budget};
+                misses += f > 2;
+            } else if (d.action == CellCachePolicy::kUse) {
+                CHECK(covered(pol, built, d.slot, cam));
+            }
+            if (d.prefetch) built[(size_t)d.prefetch_slot] = {cam, d.prefetch_budget};
+        }
+        CHECK(misses == 0);
+    }
+}
+
+int main()
+{
+    test_tile_shapes();
+    test_cell_grid();
+    test_xcd_order();
+    test_dispatch_order_static_view();
+    test_dispatch_order_moving_views();
+    test_cell_motion_bounds_direction_change();
+    test_grown_margin_inequality();
+    test_cell_cache_policy();
+    static_assert(kResidentPerCU == RTX_WAVES_PER_EU, "one constant");
+    if (g_failed) {
+        std::printf("%d check(s) failed\n", g_failed);
+        return 1;
+    }
+    std::printf("all host planning tests passed\n");
+    return 0;
+}

@@ -1,0 +1,330 @@
+"""Round 3 on the GPU: coarse-cell lists that outlive a frame (RTX_OPT_CELL_REUSE), the XCD-aware dispatch order of two-level
+grids (RTX_OPT_XCD_ORDER), HIP graphs that refuse a scene they were not recorded on, and dispatch orders frozen by a recorded
+launch.  The reference has none of these (its Culling kernel is an empty stub, RayTracingManager.cu:46-51, and it launches
+one kernel per frame on the default stream, :127-134); what they must preserve is the frame, byte for byte -- checked against
+the brute kernel (every pixel tests every object, RayTracing.cu:100-136) and, where it is quick enough, the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle as O
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    return U.pkg()
+
+
+def _stats(R, c):
+    return {k: c.get_option(v) for k, v in (("builds", R.STAT_CELL_BUILDS), ("prefetches", R.STAT_CELL_PREFETCHES),
+                                            ("hits", R.STAT_CELL_HITS), ("per_frame", R.STAT_CELL_PER_FRAME))}
+
+
+def _dense_scene(R, W, H, n, seed):
+    p = R.camera_params(W, H)
+    sph, _ = R.synth_scene(seed, n, 0, p.element1, p.element2)
+    return sph, np.zeros((0, 11), dtype=np.float32)
+
+
+def _pair(R, W, H, sph, pl):
+    """(context under test, brute-kernel context of the same scene)."""
+    a, b = R.Context(W, H), R.Context(W, H)
+    for c in (a, b):
+        c.set_scene(sph, pl)
+    b.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+    return a, b
+
+
+def _frame(c, p, mode, buf, stream=None):
+    import torch
+    buf.fill_(0xEE)
+    torch.cuda.synchronize()
+    c.render_rows(p, mode, 0, int(p.y), d_out=buf.data_ptr(), out_row_base=0, stream=stream,
+                  flags=0 if mode >= O.RGB_ASCII else 1)
+
+
+@pytest.mark.parametrize("seed,n,W,H", [(5, 8192, 640, 360), (11, 3000, 480, 270), (13, 2600, 1280, 720)])
+def test_cell_lists_reused_across_a_moving_camera_equal_the_brute_kernel(R, seed, n, W, H):
+    """A camera that rests, creeps (turning and translating), races and rests again: every frame -- served by cached lists,
+    by lists built ahead of time on the side stream, by an in-line rebuild or by the per-frame pre-pass -- equals the brute
+    kernel's frame of the same camera, and each of those four ways is actually taken."""
+    import torch
+    sph, pl = _dense_scene(R, W, H, n, seed)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        assert a.get_option(R.OPT_CELL_REUSE) == -1            # on by default
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        yaw, pos = math.pi, [0.0, 0.0, 0.0]
+        phases = [("rest", 12, 0.0, 0.0), ("creep", 60, 4.0e-4, 0.01), ("race", 8, 0.03, 0.5), ("rest", 10, 0.0, 0.0),
+                  ("creep back", 40, -7.0e-4, -0.02)]
+        seen = {}
+        for name, frames, dyaw, dpos in phases:
+            s0 = _stats(R, a)
+            for f in range(frames):
+                yaw += dyaw
+                pos[0] += dpos
+                pos[2] += 0.5 * dpos
+                p = R.camera_params(W, H, pos=tuple(pos), rot=(0.0, yaw, 0.0))
+                for mode in ((O.RGB_ASCII,) if f % 7 else (O.RGB_ASCII, O.BIT_ASCII)):
+                    _frame(a, p, mode, got)
+                    _frame(b, p, mode, want)
+                    torch.cuda.synchronize()
+                    assert torch.equal(got, want), "%s frame %d mode %d: %s" % (name, f, mode, U.first_diff(got.cpu().numpy(), want.cpu().numpy(), 20 if mode >= 2 else 12, W))
+            s1 = _stats(R, a)
+            seen[name] = {k: s1[k] - s0[k] for k in s1}
+        assert "binned" in a.last_kernel or "true" in a.last_kernel
+        assert seen["rest"]["builds"] <= 1 and seen["rest"]["hits"] >= 9 and seen["rest"]["per_frame"] == 0
+        assert seen["creep"]["prefetches"] >= 3 and seen["creep"]["per_frame"] == 0 and seen["creep"]["hits"] >= 50
+        assert seen["race"]["per_frame"] >= 6                  # too fast for reuse: the per-frame pre-pass
+        assert seen["creep back"]["hits"] >= 30
+    finally:
+        a.close()
+        b.close()
+
+
+def test_cell_lists_shared_by_frames_in_flight_on_several_streams(R):
+    """Four render streams, frames queued without waiting, the camera creeping: lists built on one stream (or the side stream)
+    serve launches on the others; every frame of the ring equals the brute kernel's."""
+    import torch
+    W, H, n = 640, 360, 6000
+    sph, pl = _dense_scene(R, W, H, n, 21)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        ring = [torch.empty(20 * W * H, dtype=torch.uint8, device="cuda") for _ in range(24)]
+        want = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        frame_no = 0
+        for rnd in range(6):
+            for r in ring:
+                r.fill_(0xEE)
+            torch.cuda.synchronize()
+            cams = []
+            for i, r in enumerate(ring):
+                step = 3.0e-4 if rnd % 2 == 0 else 0.0
+                frame_no += 1
+                p = R.camera_params(W, H, pos=(0.002 * frame_no, 0.0, 0.0), rot=(0.0, math.pi + step * frame_no, 0.0))
+                cams.append(p)
+                a.render_rows(p, O.RGB_ASCII, 0, H, d_out=r.data_ptr(), out_row_base=0, stream=streams[i % 4].cuda_stream)
+            torch.cuda.synchronize()
+            for i, r in enumerate(ring):
+                _frame(b, cams[i], O.RGB_ASCII, want)
+                torch.cuda.synchronize()
+                assert torch.equal(r, want), "round %d frame %d" % (rnd, i)
+        s = _stats(R, a)
+        assert s["hits"] > 100 and s["prefetches"] >= 2
+    finally:
+        a.close()
+        b.close()
+
+
+def test_cell_lists_with_bouncing_spheres(R):
+    """rtx_update_objects between frames (Sphere::Update, Sphere.cu:15-23): the first step after an edit may move a sphere
+    from anywhere onto +-10 and counts as an edit; later steps move a sphere by at most |speed dt|, which the lists' position
+    budget covers.  Every frame equals the brute kernel's on a twin context stepped alike; the last one the oracle's."""
+    import torch
+    W, H, n = 320, 180, 2600
+    rng = np.random.default_rng(3)
+    sph = np.concatenate([rng.uniform(-60, 60, (n, 1)), rng.uniform(-25, 25, (n, 1)), rng.uniform(30, 160, (n, 1)),
+                          rng.uniform(0.3, 2.0, (n, 1)), np.floor(rng.uniform(1, 256, (n, 3)))], axis=1).astype(np.float32)
+    pl = np.zeros((0, 11), dtype=np.float32)
+    a, b = _pair(R, W, H, sph, pl)
+    sc = O.Scene.from_arrays(sph, pl)
+    try:
+        speeds = (rng.integers(100, 400, n) / 100.0).astype(np.float32)
+        for i in range(n):
+            for c in (a, b):
+                c.set_sphere_motion(i, -1, float(speeds[i]))
+            sc.objects()[i].speed = float(speeds[i])
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        p = R.camera_params(W, H)
+        for f in range(40):
+            dt = (0.016, 0.033, 0.004)[f % 3]
+            for c in (a, b):
+                c.update_objects(dt)
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, dt)
+            _frame(a, p, O.RGB_ASCII, got)
+            _frame(b, p, O.RGB_ASCII, want)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), "frame %d" % f
+        s = _stats(R, a)
+        assert s["hits"] >= 25 and s["per_frame"] == 0
+        assert np.array_equal(got.cpu().numpy(), O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8))
+    finally:
+        a.close()
+        b.close()
+
+
+def test_reuse_off_and_xcd_order_off_render_the_same_frames(R):
+    import torch
+    W, H, n = 640, 360, 8192
+    sph, pl = _dense_scene(R, W, H, n, 9)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        p = R.camera_params(W, H, pos=(1.0, 0.5, 0.0), rot=(0.02, math.pi + 0.1, 0.0))
+        _frame(b, p, O.RGB_ASCII, want)
+        for reuse, xcd in ((0, -1), (-1, 0), (0, 0), (1, 1)):
+            a.set_option(R.OPT_CELL_REUSE, reuse)
+            a.set_option(R.OPT_XCD_ORDER, xcd)
+            s0 = _stats(R, a)
+            for _ in range(3):
+                _frame(a, p, O.RGB_ASCII, got)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (reuse, xcd)
+            s1 = _stats(R, a)
+            if reuse == 0:
+                assert s1["per_frame"] - s0["per_frame"] == 3 and s1["hits"] == s0["hits"]
+            else:
+                assert s1["per_frame"] == s0["per_frame"] and s1["hits"] - s0["hits"] >= 2
+    finally:
+        a.close()
+        b.close()
+
+
+def test_config5_with_cached_lists_is_the_golden_frame(R):
+    """BASELINE config 5 at full size: the first frame bins, the following ones reuse; all equal the committed golden hash."""
+    import torch
+    p, sph, pl = R.config_inputs("C5")
+    W, H = int(p.x), int(p.y)
+    gold = U.load_golden()["C5_RGB_ASCII"]["frame_fnv1a64"]
+    c = R.Context(W, H)
+    try:
+        c.set_scene(sph, pl)
+        buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        for i in range(4):
+            _frame(c, p, O.RGB_ASCII, buf)
+            torch.cuda.synchronize()
+            assert O.fnv1a64(buf.cpu().numpy()) == gold, "frame %d" % i
+        s = _stats(R, c)
+        assert s["builds"] == 1 and s["hits"] == 3 and s["per_frame"] == 0
+    finally:
+        c.close()
+
+
+def test_recorded_graph_is_refused_after_a_scene_edit(R):
+    """A recorded launch keeps raw pointers into the scene arrays and the object counts of the moment it was recorded:
+    after rtx_scene_add_* (here: enough spheres to make the store reallocate) rtx_graph_launch must refuse the graph
+    instead of replaying kernels that read freed memory; rtx_update_objects moves spheres in place and is fine."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    c = R.Context(W, H)
+    try:
+        c.set_scene(sph, pl)
+        st = torch.cuda.Stream()
+        buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)   # uploads the scene
+        torch.cuda.synchronize()
+        want = buf.clone()
+        c.graph_begin(st.cuda_stream)
+        c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        g = c.graph_end(st.cuda_stream)
+        buf.fill_(0xEE)
+        torch.cuda.synchronize()
+        c.graph_launch(g, st.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
+        # recorded launches need caller buffers: the context's own frame is refused, and the stream leaves capture usable
+        c.graph_begin(st.cuda_stream)
+        with pytest.raises(R.RtxError) as e:
+            c.render_rows(p, O.RGB_ASCII, 0, H, stream=st.cuda_stream)
+        assert e.value.status == R.ERR_INVALID_ARGUMENT
+        try:
+            c.graph_destroy(c.graph_end(st.cuda_stream))
+        except R.RtxError:
+            pass
+        # more than 1024 new spheres: the device arrays are reallocated and the old ones freed
+        extra = np.concatenate([np.random.default_rng(1).uniform(-50, 50, (1500, 3)), np.full((1500, 1), 0.5), np.full((1500, 3), 200.0)],
+                               axis=1).astype(np.float32)
+        c.add_spheres(extra)
+        with pytest.raises(R.RtxError) as e:
+            c.graph_launch(g, st.cuda_stream)
+        assert e.value.status == R.ERR_INVALID_ARGUMENT and "re-capture" in str(e.value)
+        c.graph_destroy(g)
+        # a fresh recording on the edited scene works, and physics steps do not invalidate it
+        c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        c.graph_begin(st.cuda_stream)
+        c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        g2 = c.graph_end(st.cuda_stream)
+        c.update_objects(0.01)
+        c.synchronize()
+        c.graph_launch(g2, st.cuda_stream)
+        torch.cuda.synchronize()
+        c.graph_destroy(g2)
+    finally:
+        c.close()
+
+
+def test_recorded_launch_runs_under_the_converged_order_which_is_then_frozen(R):
+    """A grid's dispatch order converges over its first launches on a stream (rtx_balance_tiles); a launch recorded after that
+    keeps the order's address, so the library stops deriving orders for that (stream, grid): replays interleaved with a
+    hundred direct launches on the same stream all render the golden frame, and no further pass is queued."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    gold = U.load_golden()["C2_RGB_ASCII"]["frame_fnv1a64"]
+    c = R.Context(W, H)
+    try:
+        c.set_scene(sph, pl)
+        st = torch.cuda.Stream()
+        buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        buf2 = torch.empty_like(buf)
+        for _ in range(90):
+            c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        passes = c.get_option(R.STAT_ORDER_PASSES)
+        assert passes >= 10 and c.get_option(R.STAT_ORDERS_FROZEN) == 0
+        c.graph_begin(st.cuda_stream)
+        c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        g = c.graph_end(st.cuda_stream)
+        assert c.get_option(R.STAT_ORDERS_FROZEN) == 1
+        for i in range(6):
+            buf.fill_(0xEE)
+            torch.cuda.synchronize()
+            c.graph_launch(g, st.cuda_stream)
+            for _ in range(20):   # direct launches of the same grid on the same stream, in between and in flight with the replays
+                c.render_rows(p, O.RGB_ASCII, 0, H, d_out=buf2.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+            c.graph_launch(g, st.cuda_stream)
+            torch.cuda.synchronize()
+            assert O.fnv1a64(buf.cpu().numpy()) == gold and torch.equal(buf, buf2), "replay %d" % i
+        assert c.get_option(R.STAT_ORDER_PASSES) == passes      # frozen: nothing was derived any more
+        c.graph_destroy(g)
+    finally:
+        c.close()
+
+
+def test_two_orders_alternating_on_one_stream_each_converge(R):
+    """Order buffers are kept per (stream, tile grid): two slabs of a frame alternating on one stream each keep their own set
+    (before round 3 every launch reset the stream's only set, queued a pass and made the next launch wait for it)."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    c = R.Context(W, H)
+    b = R.Context(W, H)
+    try:
+        for x in (c, b):
+            x.set_scene(sph, pl)
+        b.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        st = torch.cuda.Stream()
+        buf = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(buf)
+        b.render_rows(p, O.RGB_ASCII, 0, H, d_out=want.data_ptr(), out_row_base=0)
+        b.synchronize()
+        for i in range(120):
+            c.render_rows(p, O.RGB_ASCII, 0, 540, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+            c.render_rows(p, O.RGB_ASCII, 540, 540, d_out=buf.data_ptr(), out_row_base=0, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(buf, want)
+        passes = c.get_option(R.STAT_ORDER_PASSES)
+        assert 20 <= passes <= 120     # both grids went through their settling passes; not one pass per launch
+    finally:
+        c.close()
+        b.close()

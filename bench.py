@@ -491,11 +491,11 @@ def run_single(args, torch, R):
     # library learns on a static view (rtx_balance_tiles) has nothing to learn from here; these are the rates a caller
     # whose camera never rests sees.  Outside the graded number, after the verification copy.
     if args.what == "trace" and not args.no_moving_view:
-        NMV = 1000
-        cams = moving_cameras(R, W, H, NMV)
+        NMV = 1000 if 1000 % F == 0 else 1200          # a multiple of the frames in flight (1200: of 1..6, 8, 10, 12)
+        cams = moving_cameras(R, W, H, NMV, amplitude=NMV // 4 * MOVING_STEP_RAD)
         counter = [0]
         mv = {"step_rad_per_frame": MOVING_STEP_RAD, "views": NMV,
-              "what": "batches of the same K frames, yaw on a triangle wave of +-0.25 rad, every frame %g rad from the one before" % MOVING_STEP_RAD}
+              "what": "batches of the same K frames, yaw on a triangle wave of +-%.2f rad, every frame %g rad from the one before" % (NMV // 4 * MOVING_STEP_RAD, MOVING_STEP_RAD)}
         if F > 1:
             ring = ctx.make_submitter(cams, mode, [fbufs[i % F].data_ptr() for i in range(NMV)], [streams[i % F].cuda_stream for i in range(NMV)])
 

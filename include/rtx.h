@@ -113,7 +113,9 @@ enum rtx_stat {
     RTX_STAT_CELL_HITS = 103,       /* launches served by cached lists */
     RTX_STAT_CELL_PER_FRAME = 104,  /* launches that binned for themselves alone (reuse off, or a fast camera) */
     RTX_STAT_ORDER_PASSES = 105,    /* dispatch-order passes queued (rtx_balance_tiles / rtx_order_tiles) */
-    RTX_STAT_ORDERS_FROZEN = 106    /* dispatch orders a recorded launch reads (kept as they are from then on) */
+    RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a recorded launch reads (kept as they are from then on) */
+    RTX_STAT_CELL_CAPACITY_FLOOR = 107 /* entries per cell list the current grid is planned with at least (0: the default capacity has
+                                     * sufficed); grown from the longest list the binning passes report */
 };
 
 /* Flags of rtx_render_rows. */

@@ -88,12 +88,20 @@ struct rtx_ctx {
         hipEvent_t ev_built = nullptr;
         bool ever_built = false;
         bool built_on_aux = false;              // the last build ran on the side stream
+        bool known_ready = false;               // the last build is known to have finished (hipEventQuery said so once)
         std::vector<hipStream_t> waited;        // streams that are already ordered after the last build
         std::vector<hipStream_t> readers;       // streams that have queued launches reading this set since the last build
         std::vector<hipEvent_t> reader_events;  // pool: one per reader, for ordering a rebuild after them
     };
     CellCacheSlot cell_cache[2];
     rtxplan::CellCachePolicy cell_policy;
+    // capacity feedback: the binning passes keep the longest list needed in d_cell_max; it is copied to the pinned word
+    // h_cell_max after a build (and now and then on the per-frame path) and read, unsynchronised, when the next launch is planned
+    uint32_t* d_cell_max = nullptr;
+    volatile uint32_t* h_cell_max = nullptr;
+    uint32_t cell_cap_floor = 0;                // capacity the lists of the current grid are planned with at least
+    uint64_t cell_grid_id[3] = {0, 0, 0};       // the grid (and scene generation) the two words above belong to
+    uint64_t per_frame_bins = 0;
     uint32_t* xcd_order = nullptr;              // static dispatch order of a two-level grid: a cell's tiles share an XCD
     size_t xcd_order_cap = 0;
     uint64_t xcd_order_key[2] = {0, 0};

@@ -52,6 +52,7 @@ struct KArgs {
     // cameras whose ray directions differ by at most bin_theta (chord of unit vectors) and whose position -- sphere
     // motion counted in -- by at most bin_delta from this launch's.  0, 0: this camera only.
     float bin_theta, bin_delta;
+    uint32_t* cell_max_out;   // rtx_bin_cells: the longest list any cell has needed so far (atomicMax; past half the capacity only), or nullptr
     // Heaviest-first dispatch (speed only; any permutation of the macro tiles renders the same frame): tile_order[b] =
     // bx | by << 16 of the macro tile that workgroup b (linear block index, x fastest) renders, built by
     // rtx_order_tiles / rtx_balance_tiles from tile_cost, the work estimate every workgroup of an earlier launch left
@@ -64,10 +65,10 @@ struct KArgs {
     uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;
                               // 2 = RTX_RENDER_VALUES: out holds 8 floats per pixel (distance, shadingValue, normal, colour)
-#ifdef RTX_ABLATE
-    uint32_t ablate;          // experiment builds only (make ablate): bit mask of stages to skip
-    unsigned long long* stamps; // experiment builds only: 16 timestamps per workgroup (s_memtime), or nullptr
-#endif
+    // (experiment build only: its extra arguments; nothing in the product build)
+#define RTX_X_SECTION_KARGS
+#include "rtx_experiment.inc"
+#undef RTX_X_SECTION_KARGS
 };
 
 // Arguments of rtx_expand_words (compact pixel words -> records), by value.

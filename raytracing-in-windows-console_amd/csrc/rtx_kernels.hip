@@ -17,28 +17,15 @@
 #include "rtx_device.hpp"
 #include "rtx_kernels.h"
 
-#include <cstdio>
-#include <cstdlib>
+// The experiment build's hooks (ABL, STAMP, RTX_X_*): empty / constant false in the product build.
+#define RTX_X_SECTION_DEVICE
+#include "rtx_experiment.inc"
+#undef RTX_X_SECTION_DEVICE
+#define RTX_X_SECTION_HOST
+#include "rtx_experiment.inc"
+#undef RTX_X_SECTION_HOST
 
 namespace rtx {
-
-// Timing experiments only (make ablate -> librtx_hip_ablate.so, never shipped): ABL(bit) is true when
-// the stage is to be skipped.  In the product build it is the constant false.
-#ifdef RTX_ABLATE
-#define ABL(bit) ((a.ablate & (bit)) != 0u)
-// wave 0 of each workgroup stamps the shader clock into its slot of a.stamps (diagnostic build only)
-#define STAMP(i)                                                                                            \
-    do {                                                                                                    \
-        if (a.stamps && threadIdx.x == 0 && !(a.ablate & 0x8000u)) { /* 0x8000: start/end stamps only */     \
-            unsigned long long t__;                                                                         \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                    \
-            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = t__;                         \
-        }                                                                                                   \
-    } while (0)
-#else
-#define ABL(bit) false
-#define STAMP(i) do { } while (0)
-#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding
 // global loads (s_waitcnt vmcnt(0)), which would expose the latency of every prefetch in flight; in
@@ -385,9 +372,7 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
 {
     float s;
     const bool rejected = sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s);
-#ifdef RTX_ABLATE
-    bool updated = false;
-#endif
+    RTX_X_CANDIDATE_BEGIN();
     if (!rejected) {
         if (!HOISTED) ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
         float t;
@@ -396,16 +381,11 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
             if (t < best.t || (t == best.t && ki < best.k)) {
                 best.t = t;
                 best.k = ki;
-#ifdef RTX_ABLATE
-                updated = true;
-#endif
+                RTX_X_CANDIDATE_UPDATED();
             }
         }
     }
-#ifdef RTX_ABLATE
-    // diagnostic: candidates some lane of this wave takes to the exact test; of those, how many change no lane's best hit
-    slow += (__ballot(!rejected) != 0ull ? 1u : 0u) + ((__ballot(!rejected) != 0ull && __ballot(updated) == 0ull) ? 0x10000u : 0u);
-#endif
+    RTX_X_CANDIDATE_END(rejected, slow);
 }
 template <bool HOISTED>
 __device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best, uint32_t& slow)
@@ -608,17 +588,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     cam.fW = a.fW; cam.fH = a.fH;
 
     STAMP(0);
-#ifdef RTX_ABLATE
-    if (a.stamps && threadIdx.x == 0) {
-        unsigned hwid, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long rt;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-        a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 14] = ((unsigned long long)xcc << 32) | hwid;
-        a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 15] = rt;
-    }
-#endif
+    RTX_X_WG_BEGIN();
     // what this workgroup stages: the whole scene, or its coarse cell's list (two-level culling)
     Items items;
     items.geom = a.sph_geom;
@@ -656,11 +626,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     if (tid == 0u) {
         s_cost[0] = 0u;
         s_cost[1] = 0u;
-#ifndef RTX_NO_START_STAMP
         if (a.tile_cost != nullptr) {
             s_cost[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock per XCD: when this workgroup started
         }
-#endif
     }
     if (tid < mw) {
         // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
@@ -747,13 +715,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
         const float hw = pla.w * 0.5f, hh = plb.w * 0.5f;
         const float4 bounds = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
-#ifdef RTX_NO_PLANE_CULL // experiment builds: every plane enters the table
-        const bool listed = tid < np_tab;
-#else
         // (from two planes on: with a single plane the test costs the workgroup what leaving the plane out saves --
         // measured at C2, 19.9 vs 20.2 us per frame)
         const bool listed = tid < np_tab && !(CULL && np >= 2u && !ABL(128u) && plane_invisible(cam, mcol0, mrow0, mw, mh, n, num, bounds));
-#endif
         const unsigned long long m = __ballot(listed);
         if (listed) {
             const uint32_t at = (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
@@ -773,9 +737,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // wave whose pixels miss everything moves on while its neighbour shades, was measured and dropped: +6 % per frame --
     // profiles/r02_c_single_launch_experiments.md.)
     uint32_t wcost = 0; // this wave's work estimate for the heaviest-first order (wave-uniform)
-#ifdef RTX_ABLATE
-    unsigned long long wfeat = 0; // diagnostic: slow-path entries, passes with a hit, passes, candidates, passes with a plane hit
-#endif
+    RTX_X_WAVE_FEATURES();
     const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
 #pragma unroll 1
     for (uint32_t j = 0; j < nsub; j++) {
@@ -969,30 +931,9 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         // and the hit tests' slow path when the wave sees anything (instruction counts of tools/ablate_pmc_gpu.sh)
         wcost += kCostPass + kCostCandidate * scanned + (__ballot(in_frame && distance <= cam.far) != 0ull ? kCostShaded : 0u);
         STAMP(3 + (j < 9u ? j : 9u));
-#ifdef RTX_ABLATE
-        wfeat += ((unsigned long long)(slow & 0xffffu) << 20) | ((__ballot(in_frame && distance <= cam.far) != 0ull ? 1ull : 0ull) << 32) | (1ull << 36) |
-                 ((unsigned long long)scanned << 40) | ((unsigned long long)(slow >> 16) << 52);
-        if (a.stamps && threadIdx.x == 0) {
-            unsigned long long rt;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 13] = rt; // end of the latest pass
-            a.stamps[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16 + 12] = ((unsigned long long)total << 32) | wcost;
-        }
-#endif
+        RTX_X_PASS_END(slow, __ballot(in_frame && distance <= cam.far) != 0ull, scanned, total, wcost);
     }
-#ifdef RTX_ABLATE
-    // light stamps: every wave leaves its SIMD (HW_ID), its end time and its work estimate in slots 0-3, 4-7, 8-11
-    if (a.stamps && (a.ablate & 0x8000u) && (threadIdx.x & 63u) == 0u) {
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned long long rt;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt)::"memory");
-        unsigned long long* slot = a.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
-        slot[threadIdx.x >> 6] = hwid;
-        slot[4 + (threadIdx.x >> 6)] = rt;
-        slot[8 + (threadIdx.x >> 6)] = wfeat | wcost;
-    }
-#endif
+    RTX_X_KERNEL_END(wcost);
     // ---- leave this tile's work estimate for rtx_order_tiles: the sum over the four waves, stored by the last one
     // to get here (LDS atomics of one wave execute in order, so the fourth increment sees all four sums)
     // (lane number from mbcnt: keeping tid & 63 alive across the whole kernel for this one test costs a register)
@@ -1004,9 +945,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             const uint32_t n_tiles = gridDim.x * gridDim.y, pos = blockIdx.y * gridDim.x + blockIdx.x;
             a.tile_cost[by * gridDim.x + bx] = *reinterpret_cast<volatile uint32_t*>(&s_cost[0]);
             a.tile_cost[n_tiles + pos] = *reinterpret_cast<volatile uint32_t*>(&s_cost[2]);
-#ifndef RTX_NO_END_STAMP
             a.tile_cost[2u * n_tiles + pos] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
         }
     }
 }
@@ -1066,6 +1005,9 @@ __device__ __forceinline__ void bin_cells_of_block(const KArgs& a, const float4*
     __syncthreads();
     if (tid < (uint32_t)kBlockCells && s_cnt[tid] != 0u) {
         s_base[tid] = atomicAdd(a.cell_count_out + s_cellid[tid], s_cnt[tid]); // one reservation per cell and flush
+        // capacity feedback for the host (rtx_plan.hpp, cell_capacity_wanted): only lists past half their capacity report
+        const uint32_t need = s_base[tid] + s_cnt[tid];
+        if (a.cell_max_out != nullptr && need > (a.cell_cap >> 1)) atomicMax(a.cell_max_out, need);
     }
     __syncthreads();
     for (uint32_t p = tid, i = 0; p < pairs; p += (uint32_t)kThreads, i++) {
@@ -1316,12 +1258,7 @@ __global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t*
 //             group with the k-th smallest sum so far.
 // Any permutation renders the same frame; every position receives exactly one tile whatever the inputs hold (ranks come
 // from counting, positions from ranks).
-#ifdef RTX_ABLATE
-__device__ unsigned long long g_bal_stamps[16];
-#define BSTAMP(i) do { if (threadIdx.x == 0) { g_bal_stamps[i] = __builtin_readcyclecounter(); } } while (0)
-#else
-#define BSTAMP(i) do { } while (0)
-#endif
+RTX_X_BALANCE_STAMPS();
 // The pass runs beside the next frame's trace launch (a stream of its own), so it is shaped to fit into a slot that
 // launch leaves free: 256 threads, the trace kernel's register budget, under 38 KB of LDS -- a CU holding six trace
 // workgroups has room for exactly that.  (As one 1024-thread workgroup it needed a CU to itself and the frame beside it
@@ -1652,10 +1589,7 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
     const uint32_t rows = a->row_end - a->row0;
     dim3 grid((a->W + mw - 1u) / mw, (rows + mh - 1u) / mh, 1), block(kThreads, 1, 1);
     const char* name = nullptr;
-    unsigned lds_pad = 0; // experiment builds: extra dynamic LDS per workgroup, to cap the workgroups a CU holds
-#ifdef RTX_ABLATE
-    if (const char* e = getenv("RTX_LDS_PAD")) lds_pad = (unsigned)strtoul(e, nullptr, 0);
-#endif
+    const unsigned lds_pad = rtx_x_lds_pad(); // 0 in the product build
 #define RTX_LAUNCH(M, C, O, SUFFIX)                                                          \
     do {                                                                                     \
         if (C && a->refine) {                                                                \
@@ -1731,23 +1665,10 @@ extern "C" int rtx_k_launch_balance_tiles(const uint32_t* tile_cost, uint32_t n_
     if (n_tiles == 0 || n_tiles > (uint32_t)rtx::kBalanceMaxTiles || gx == 0 || n_cu == 0 || n_cu > (uint32_t)rtx::kOrderThreads) {
         return (int)hipErrorInvalidValue;
     }
-#ifdef RTX_ABLATE
-    if (getenv("RTX_BAL_DEBUG")) {
-        static int calls = 0;
-        if (++calls == 12) {
-            unsigned long long h[16];
-            hipDeviceSynchronize();
-            hipMemcpyFromSymbol(h, HIP_SYMBOL(rtx::g_bal_stamps), sizeof h);
-            for (int i = 1; i < 7; i++) fprintf(stderr, "balance phase %d: %llu clocks\n", i, h[i] - h[i - 1]);
-        }
-    }
-#endif
+    RTX_X_BALANCE_DEBUG();
     // how much of a group's deviation from the mean duration goes into its tiles' factors per pass, and the largest step
     float damping = 0.7f, max_step = 0.18f;
-#ifdef RTX_ABLATE
-    if (const char* e = getenv("RTX_BAL_DAMPING")) damping = (float)atof(e);
-    if (const char* e = getenv("RTX_BAL_MAX_STEP")) max_step = (float)atof(e);
-#endif
+    RTX_X_BALANCE_PARAMS(damping, max_step);
     hipLaunchKernelGGL(rtx::rtx_balance_tiles, dim3(1), dim3(rtx::kBalanceThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, prev_order,
                        factor, (uint32_t)have_factor, (uint32_t)have_times, tile_order, damping, max_step);
     return (int)hipGetLastError();

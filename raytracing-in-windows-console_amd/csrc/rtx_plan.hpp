@@ -197,7 +197,7 @@ struct CellGrid {
 // Two-level culling for large scenes: coarse cells of 2^gx x 2^gy macro tiles -- about 256 of them, about 1024 from
 // 16384 spheres on, where shorter cell lists save the trace workgroups a staging step -- binned by ONE pre-pass launch
 // (rtx_bin_cells: blocks of 4 x 4 cells, then the cells of each block).
-inline CellGrid plan_cells(const TileShape& t, uint32_t ns, double aspect, int64_t opt_cell_capacity)
+inline CellGrid plan_cells(const TileShape& t, uint32_t ns, double aspect, int64_t opt_cell_capacity, uint32_t cap_floor = 0)
 {
     CellGrid c;
     const uint32_t tiles_x = t.grid_x, tiles_y = t.grid_y;
@@ -221,7 +221,10 @@ inline CellGrid plan_cells(const TileShape& t, uint32_t ns, double aspect, int64
     // Entries per cell list: four times the share of a uniform scene plus a floor, so that the scratch is O(spheres) --
     // 4 ns + 1024 cells words -- instead of cells x ns.  A cell that needs more (a clustered scene) falls back to
     // staging the whole scene: slower, never wrong.
+    // `cap_floor`: what the longest list of this grid was seen to need (cell_capacity_wanted below): a view that packs the
+    // scene into a few cells grows the lists instead of falling off the whole-scene cliff frame after frame.
     uint32_t cap = opt_cell_capacity > 0 ? (uint32_t)opt_cell_capacity : (uint32_t)(4ull * ns / c.n_cells) + 1024u;
+    if (opt_cell_capacity <= 0 && cap < cap_floor) cap = cap_floor;
     if (cap > ns) cap = ns; // a list never holds more than the scene
     if (cap == 0) cap = 1;
     c.cap = cap;
@@ -267,6 +270,18 @@ inline void xcd_cell_order(uint32_t grid_x, uint32_t grid_y, uint32_t gx, uint32
             }
         }
     }
+}
+
+// Capacity feedback: `seen` is the longest list any cell of the grid has needed so far (the binning pass keeps counting
+// past the capacity and reports the maximum), `cap` the capacity in use.  Returns the floor to plan with from now on:
+// unchanged while the lists have a fifth to spare, else 1.5 x seen rounded up to 256 entries (a growth step reallocates the
+// lists behind a device synchronisation: few, large steps).
+inline uint32_t cell_capacity_wanted(uint32_t seen, uint32_t cap, uint32_t floor_now)
+{
+    if ((uint64_t)seen * 5u <= (uint64_t)cap * 4u) return floor_now;
+    const uint64_t want = ((uint64_t)seen * 3u / 2u + 64u + 255u) / 256u * 256u;
+    const uint32_t w = want > 0xffffffffull ? 0xffffffffu : (uint32_t)want;
+    return w > floor_now ? w : floor_now;
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch order
@@ -535,7 +550,10 @@ public:
     const CellBudget& slot_budget(int s) const { return slot_[s].budget; }
 
     // cell_tan_w / cell_tan_h: a cell's extent on the view plane (tangent units); the cap on the rotation budget.
-    Decision decide(const CellKey& key, const CellCamera& cam, double cell_tan_w, double cell_tan_h)
+    // ready[s]: the build of slot s has finished on the device (a slot still being built ahead of time is used only if
+    // nothing finished covers the camera: switching to it at once would make every render stream wait for the build and
+    // take the overlap away).
+    Decision decide(const CellKey& key, const CellCamera& cam, double cell_tan_w, double cell_tan_h, const bool ready[2])
     {
         Decision d;
         // the step from the previous frame (whatever path that one took) sets the budgets of anything built now
@@ -555,17 +573,19 @@ public:
 
         int best = -1;
         float best_used = 2.0f;
+        bool best_ready = false;
         for (int s = 0; s < 2; s++) {
             if (!slot_[s].valid || !(slot_[s].key == key)) continue;
             const CellBudget m = cell_motion(slot_[s].built_for, cam);
             if (!(m.theta <= slot_[s].budget.theta) || !(m.delta <= slot_[s].budget.delta)) continue;
-            // fraction of the budget used: prefer the fresher lists
+            // fraction of the budget used: prefer finished lists, then the fresher ones
             const float ut = slot_[s].budget.theta > 0.0f ? m.theta / slot_[s].budget.theta : 0.0f;
             const float ud = slot_[s].budget.delta > 0.0f ? m.delta / slot_[s].budget.delta : 0.0f;
             const float used = std::fmax(ut, ud);
-            if (used < best_used) {
+            if (best < 0 || (ready[s] && !best_ready) || (ready[s] == best_ready && used < best_used)) {
                 best_used = used;
                 best = s;
+                best_ready = ready[s];
             }
         }
         if (best >= 0) {

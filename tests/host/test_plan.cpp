@@ -377,6 +377,8 @@ static void test_grown_margin_inequality()
     }
 }
 
+static const bool kReady[2] = {true, true};
+
 static void test_cell_cache_policy()
 {
     CellKey key;
@@ -400,7 +402,7 @@ static void test_cell_cache_policy()
         int builds = 0, hits = 0;
         for (int f = 0; f < 100; f++) {
             const CellCamera cam = cell_camera(3.14159265, 0, 0, 0);
-            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch, kReady);
             if (d.action == CellCachePolicy::kBuild) {
                 builds++;
                 CHECK(d.budget.theta == 0.0f && d.budget.delta == 0.0f);
@@ -420,7 +422,7 @@ static void test_cell_cache_policy()
         int builds = 0, hits = 0, prefetches = 0, per_frame = 0;
         for (int f = 0; f < 600; f++) {
             const CellCamera cam = cell_camera(3.14159265 + step * f, (float)(0.01 * f), 0, 0, 0.002 * f);
-            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch, kReady);
             if (d.action == CellCachePolicy::kBuild) {
                 builds++;
                 built[(size_t)d.slot] = {cam, d.budget};
@@ -445,7 +447,7 @@ static void test_cell_cache_policy()
         CellCachePolicy pol;
         int per_frame = 0;
         for (int f = 0; f < 50; f++) {
-            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch);
+            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch, kReady);
             per_frame += d.action == CellCachePolicy::kPerFrame;
             CHECK(!d.prefetch);
         }
@@ -454,10 +456,10 @@ static void test_cell_cache_policy()
     // ... and when it comes to rest the lists are built again
     {
         CellCachePolicy pol;
-        for (int f = 0; f < 20; f++) pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch);
+        for (int f = 0; f < 20; f++) pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch, kReady);
         int builds = 0, hits = 0;
         for (int f = 0; f < 20; f++) {
-            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.2, 0, 0, 0), cw, ch);
+            const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.2, 0, 0, 0), cw, ch, kReady);
             builds += d.action == CellCachePolicy::kBuild;
             hits += d.action == CellCachePolicy::kUse;
         }
@@ -467,19 +469,49 @@ static void test_cell_cache_policy()
     {
         CellCachePolicy pol;
         const CellCamera cam = cell_camera(3.14159265, 0, 0, 0);
-        CHECK(pol.decide(key, cam, cw, ch).action == CellCachePolicy::kBuild);
-        CHECK(pol.decide(key, cam, cw, ch).action == CellCachePolicy::kUse);
+        CHECK(pol.decide(key, cam, cw, ch, kReady).action == CellCachePolicy::kBuild);
+        CHECK(pol.decide(key, cam, cw, ch, kReady).action == CellCachePolicy::kUse);
         CellCamera edited = cam;
         edited.scene_gen = 2;
-        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kBuild); // (an edit is not a fast camera: rebuilt at once)
-        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kUse);
+        CHECK(pol.decide(key, edited, cw, ch, kReady).action == CellCachePolicy::kBuild); // (an edit is not a fast camera: rebuilt at once)
+        CHECK(pol.decide(key, edited, cw, ch, kReady).action == CellCachePolicy::kUse);
         CellKey other = key;
         other.rows = 540;
-        CHECK(pol.decide(other, edited, cw, ch).action == CellCachePolicy::kBuild);
-        CHECK(pol.decide(other, edited, cw, ch).action == CellCachePolicy::kUse);
-        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kUse);   // the first grid's lists are in the other slot still
+        CHECK(pol.decide(other, edited, cw, ch, kReady).action == CellCachePolicy::kBuild);
+        CHECK(pol.decide(other, edited, cw, ch, kReady).action == CellCachePolicy::kUse);
+        CHECK(pol.decide(key, edited, cw, ch, kReady).action == CellCachePolicy::kUse);   // the first grid's lists are in the other slot still
         pol.invalidate();
-        CHECK(pol.decide(key, edited, cw, ch).action == CellCachePolicy::kBuild);
+        CHECK(pol.decide(key, edited, cw, ch, kReady).action == CellCachePolicy::kBuild);
+    }
+    // lists being built ahead of time are not switched to while finished ones still cover the camera
+    {
+        CellCachePolicy pol;
+        int switched_early = 0, prefetched_at = -1, used_slot = -1;
+        bool ready[2] = {true, true};
+        for (int f = 0; f < 40; f++) {
+            const CellCamera cam = cell_camera(3.14159265 + 5.0e-4 * f, 0, 0, 0);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch, ready);
+            if (d.action == CellCachePolicy::kUse && prefetched_at >= 0 && f <= prefetched_at + 2 && d.slot != used_slot) switched_early++;
+            if (d.action != CellCachePolicy::kPerFrame) used_slot = d.slot;
+            if (d.prefetch && prefetched_at < 0) {
+                prefetched_at = f;
+                ready[d.prefetch_slot] = false;           // its build takes three frames
+            }
+            if (prefetched_at >= 0 && f == prefetched_at + 2) ready[0] = ready[1] = true;
+        }
+        CHECK(prefetched_at >= 0 && switched_early == 0);
+    }
+    // capacity feedback: grows past what was seen once the lists have less than a fifth to spare, never shrinks
+    CHECK(cell_capacity_wanted(100, 1509, 0) == 0);
+    CHECK(cell_capacity_wanted(1300, 1509, 0) == 2048);
+    CHECK(cell_capacity_wanted(5000, 1509, 1792) == 7680);
+    CHECK(cell_capacity_wanted(100, 1509, 1792) == 1792);
+    {
+        const TileRequest q = request(1920, 1080, 1080, 65536, true);
+        const TileShape t = plan_tiles(q);
+        CHECK(plan_cells(t, 65536, q.aspect, 0, 4096).cap == 4096);
+        CHECK(plan_cells(t, 65536, q.aspect, 0, 1u << 20).cap == 65536);   // never more than the scene
+        CHECK(plan_cells(t, 65536, q.aspect, 7, 4096).cap == 7);            // an explicit capacity is taken as is
     }
     // physics: spheres that move (drift) use the position budget like a moving camera
     {
@@ -488,7 +520,7 @@ static void test_cell_cache_policy()
         int misses = 0;
         for (int f = 0; f < 300; f++) {
             const CellCamera cam = cell_camera(3.14159265, 0, 0, 0, 0.06 * f);
-            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch);
+            const CellCachePolicy::Decision d = pol.decide(key, cam, cw, ch, kReady);
             if (d.action == CellCachePolicy::kBuild) {
                 built[(size_t)d.slot] = {cam, d.budget};
                 misses += f > 2;

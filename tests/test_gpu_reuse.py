@@ -244,6 +244,7 @@ def test_recorded_graph_is_refused_after_a_scene_edit(R):
         extra = np.concatenate([np.random.default_rng(1).uniform(-50, 50, (1500, 3)), np.full((1500, 1), 0.5), np.full((1500, 3), 200.0)],
                                axis=1).astype(np.float32)
         c.add_spheres(extra)
+        c.set_option(R.OPT_TWO_LEVEL, 0)   # (2525 spheres would switch the pre-pass on, which cannot be recorded at all)
         with pytest.raises(R.RtxError) as e:
             c.graph_launch(g, st.cuda_stream)
         assert e.value.status == R.ERR_INVALID_ARGUMENT and "re-capture" in str(e.value)
@@ -327,4 +328,53 @@ def test_two_orders_alternating_on_one_stream_each_converge(R):
         assert 20 <= passes <= 120     # both grids went through their settling passes; not one pass per launch
     finally:
         c.close()
+        b.close()
+
+
+def test_cell_capacity_grows_with_the_longest_list_instead_of_staging_the_whole_scene(R):
+    """A scene packed into a corner of the view: its cells need far more than the default capacity (4 ns / cells + 1024).
+    The binning pass reports the longest list it needed, the next launches plan with 1.5 x that, and from then on no
+    workgroup falls back to the whole scene; every frame on the way equals the brute kernel's."""
+    import torch
+    W, H, n = 640, 360, 20000
+    p = R.camera_params(W, H)
+    rng = np.random.default_rng(17)
+    # all spheres within a few degrees of one direction, 60..160 units away
+    d = rng.uniform(60, 160, n)
+    tx = 0.6 * p.element1 + rng.normal(0, 0.15, n)
+    ty = -0.3 * p.element2 + rng.normal(0, 0.05, n)
+    c = 1.0 / np.sqrt(1.0 + tx * tx + ty * ty)
+    sph = np.stack([d * c * tx, d * c * ty, d * c, rng.uniform(0.05, 0.3, n), np.floor(rng.uniform(1, 256, n)), np.floor(rng.uniform(1, 256, n)),
+                    np.floor(rng.uniform(1, 256, n))], axis=1).astype(np.float32)
+    pl = np.zeros((0, 11), dtype=np.float32)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        _frame(b, p, O.RGB_ASCII, want)
+        assert a.get_option(R.STAT_CELL_CAPACITY_FLOOR) == 0
+        for f in range(8):
+            _frame(a, p, O.RGB_ASCII, got)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), "frame %d" % f
+        floor = a.get_option(R.STAT_CELL_CAPACITY_FLOOR)
+        assert floor > 4 * n // 256 + 1024, floor      # grew past the default
+        # timing: with the grown lists a frame costs a fraction of what the whole-scene fallback cost
+        a.synchronize()
+        a.timer_start()
+        for _ in range(20):
+            a.render_rows(p, O.RGB_ASCII, 0, H, d_out=got.data_ptr(), out_row_base=0)
+        grown = a.timer_stop() / 20
+        a.set_option(R.OPT_CELL_CAPACITY, 256)          # an explicit small capacity is taken as is: the fallback path
+        for _ in range(3):
+            _frame(a, p, O.RGB_ASCII, got)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
+        a.timer_start()
+        for _ in range(20):
+            a.render_rows(p, O.RGB_ASCII, 0, H, d_out=got.data_ptr(), out_row_base=0)
+        small = a.timer_stop() / 20
+        assert grown < small, (grown, small)
+    finally:
+        a.close()
         b.close()

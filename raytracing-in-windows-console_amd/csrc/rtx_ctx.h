@@ -107,7 +107,8 @@ struct rtx_ctx {
     uint64_t xcd_order_key[2] = {0, 0};
     int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
     int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
-    uint64_t scene_gen = 1;                     // bumped by every scene edit (and by the first physics step after one)
+    uint64_t scene_gen = 1;                     // bumped by every scene edit: object counts / array addresses (recorded graphs belong to one)
+    uint64_t lists_gen = 1;                     // ... and by the first physics step after one: what cell lists belong to
     bool physics_settled = false;               // every sphere has been through Sphere::Update since the last edit (|y| <= 10)
     uint64_t stat_order_passes = 0;
     uint64_t stat_cell_builds = 0, stat_cell_prefetches = 0, stat_cell_hits = 0, stat_cell_per_frame = 0;

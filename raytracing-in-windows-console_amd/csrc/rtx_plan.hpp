@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 7 // waves per SIMD the trace kernels are compiled for (72 VGPRs)
@@ -238,38 +239,38 @@ inline CellGrid plan_cells(const TileShape& t, uint32_t ns, double aspect, int64
     return c;
 }
 
-// Static dispatch order of a two-level grid.  seq = the macro tiles cell by cell (cells row-major, a cell's tiles
-// row-major, tiles beyond the grid's edge skipped); dispatch position b takes seq[swz(b)], where swz is the bijective
-// XCD swizzle (cdna_hip_programming.md, "XCD swizzle must be bijective"): the blocks b, b + 8, b + 16, ... -- which share
-// an XCD under the round-robin placement observed on MI355X -- receive one contiguous run of seq.  order[b] = bx | by << 16.
-// Any permutation renders the same frame: the placement assumption costs speed if wrong, never a pixel.
+// Static dispatch order of a two-level grid: order[b] = bx | by << 16 of the macro tile that dispatch position b (linear
+// block index) renders.  The blocks b, b + 8, b + 16, ... share an XCD under the round-robin placement observed on MI355X
+// (b % 8 labels the blocks that share one, not the XCD's id); they are given WHOLE CELLS: cell (cx, cy) belongs to label
+// (cx + 3 cy) % 8, so that a cell's list and the spheres on it are fetched into one XCD's L2 instead of into as many as the
+// cell has tiles, while every XCD still samples cells from all over the frame (a contiguous band per XCD was measured
+// first: a view that packs the scene into one side of the frame then leaves seven XCDs waiting for the eighth).  A label's
+// tiles beyond its share of positions (cells differ in size at the grid's edge) take the positions other labels leave
+// empty.  A bijection by construction; any permutation renders the same frame: a wrong placement guess costs speed only.
 inline void xcd_cell_order(uint32_t grid_x, uint32_t grid_y, uint32_t gx, uint32_t gy, uint32_t* order)
 {
     const uint32_t n = grid_x * grid_y, nxcd = 8u;
     const uint32_t cw = 1u << gx, ch = 1u << gy;
     const uint32_t cells_x = (grid_x + cw - 1u) >> gx, cells_y = (grid_y + ch - 1u) >> gy;
-    const uint32_t q = n / nxcd, r = n % nxcd;
-    // swz(b) -> position in seq; invert on the fly: walk seq and place each entry at the b with swz(b) = i
-    uint32_t i = 0;
+    std::vector<uint32_t> mine[8], spill;
     for (uint32_t cy = 0; cy < cells_y; cy++) {
         for (uint32_t cx = 0; cx < cells_x; cx++) {
+            std::vector<uint32_t>& v = mine[(cx + 3u * cy) & 7u];
             for (uint32_t ty = cy * ch; ty < (cy + 1u) * ch && ty < grid_y; ty++) {
-                for (uint32_t tx = cx * cw; tx < (cx + 1u) * cw && tx < grid_x; tx++, i++) {
-                    // i = (xcd < r ? xcd (q+1) : r (q+1) + (xcd - r) q) + k,  b = k * 8 + xcd
-                    uint32_t xcd, k;
-                    if (i < r * (q + 1u)) {
-                        xcd = i / (q + 1u);
-                        k = i - xcd * (q + 1u);
-                    } else {
-                        const uint32_t j = i - r * (q + 1u);
-                        xcd = r + (q ? j / q : 0u);
-                        k = q ? j - (xcd - r) * q : 0u;
-                    }
-                    order[k * nxcd + xcd] = tx | (ty << 16);
-                }
+                for (uint32_t tx = cx * cw; tx < (cx + 1u) * cw && tx < grid_x; tx++) v.push_back(tx | (ty << 16));
             }
         }
     }
+    std::vector<uint32_t> holes;
+    for (uint32_t x = 0; x < nxcd; x++) {
+        const uint32_t slots = n / nxcd + (x < n % nxcd ? 1u : 0u); // positions x, x + 8, x + 16, ...
+        for (uint32_t k = 0; k < slots; k++) {
+            if (k < mine[x].size()) order[k * nxcd + x] = mine[x][k];
+            else holes.push_back(k * nxcd + x);
+        }
+        for (size_t k = slots; k < mine[x].size(); k++) spill.push_back(mine[x][k]);
+    }
+    for (size_t i = 0; i < holes.size() && i < spill.size(); i++) order[holes[i]] = spill[i];
 }
 
 // Capacity feedback: `seen` is the longest list any cell of the grid has needed so far (the binning pass keeps counting

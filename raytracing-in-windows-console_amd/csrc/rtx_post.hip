@@ -431,7 +431,8 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
     // an edit.  A dt that is not a number moves spheres to NaN: an edit as well.
     const double step = std::fabs(dt) * (double)ctx->max_speed;
     if (!ctx->physics_settled || !(step == step) || !(step < 1.0e30)) {
-        rtx_scene_edited(ctx);
+        ctx->lists_gen++; // (object counts and array addresses are what they were: recorded graphs stay valid)
+        ctx->cell_policy.invalidate();
         ctx->physics_settled = (step == step) && (step < 1.0e30);
         ctx->scene_drift += 1.0e3;
     } else {

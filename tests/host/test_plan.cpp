@@ -114,17 +114,31 @@ static void test_xcd_order()
             if (bx < gx_n && by < gy_n) seen[by * gx_n + bx]++;
         }
         CHECK(std::all_of(seen.begin(), seen.end(), [](int c) { return c == 1; }));
-        // the blocks that share an XCD (equal b % 8) cover few cells: at most their share plus the two they cut
-        const uint32_t cells_x = (gx_n + (1u << gx) - 1) >> gx;
-        const uint32_t n_cells = cells_x * ((gy_n + (1u << gy) - 1) >> gy);
-        for (uint32_t x = 0; x < 8 && n >= 64; x++) {
-            std::vector<uint32_t> cells;
-            for (uint32_t b = x; b < n; b += 8) cells.push_back(((order[b] >> 16) >> gy) * cells_x + ((order[b] & 0xffffu) >> gx));
-            std::sort(cells.begin(), cells.end());
-            cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
-            if (!(cells.size() <= n_cells / 8 + n_cells / 64 + 2)) std::printf("grid %u x %u cells 2^%u x 2^%u: xcd %u touches %zu of %u cells\n", gx_n, gy_n, gx, gy, x, cells.size(), n_cells);
-            CHECK(cells.size() <= n_cells / 8 + n_cells / 64 + 2); // (cells cut by the grid's edge hold fewer tiles)
-            CHECK(cells.back() - cells.front() + 1 == cells.size()); // a contiguous run of cells
+        // the blocks that share an XCD (equal b % 8) hold whole cells: few cells are split over two labels, every label sees about
+        // an eighth of the cells, and those come from all over the frame (every band of cell rows is represented)
+        const uint32_t cells_x = (gx_n + (1u << gx) - 1) >> gx, cells_y = (gy_n + (1u << gy) - 1) >> gy;
+        const uint32_t n_cells = cells_x * cells_y;
+        if (n < 64) continue;
+        std::vector<uint32_t> labels_of_cell(n_cells, 0);
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t cell = ((order[b] >> 16) >> gy) * cells_x + ((order[b] & 0xffffu) >> gx);
+            labels_of_cell[cell] |= 1u << (b % 8);
+        }
+        uint32_t split = 0;
+        for (uint32_t m : labels_of_cell) split += (m & (m - 1)) != 0;
+        CHECK(split <= n_cells / 8 + 8);
+        for (uint32_t x = 0; x < 8; x++) {
+            uint32_t cells = 0, rows_seen = 0;
+            std::vector<int> row_has(cells_y, 0);
+            for (uint32_t c = 0; c < n_cells; c++) {
+                if (labels_of_cell[c] & (1u << x)) {
+                    cells++;
+                    row_has[c / cells_x] = 1;
+                }
+            }
+            for (int r : row_has) rows_seen += (uint32_t)r;
+            CHECK(cells <= n_cells / 8 + n_cells / 16 + 8);
+            if (cells_x >= 8) CHECK(rows_seen == cells_y);
         }
     }
 }

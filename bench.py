@@ -534,6 +534,12 @@ def run_single(args, torch, R):
                 step_alone(i)
             alone.append(ctx.timer_stop() / max(10, min(K, 200)))
         mv["alone_ms_per_frame"] = round(median(alone), 5)
+        try:   # how the coarse-cell lists (two-level culling) were obtained over the whole run: in-line builds, builds ahead of time, launches served from cached lists, launches that binned for themselves
+            mv["cell_lists"] = {k: ctx.get_option(v) for k, v in (("builds", R.STAT_CELL_BUILDS), ("prefetches", R.STAT_CELL_PREFETCHES),
+                                                                  ("hits", R.STAT_CELL_HITS), ("per_frame", R.STAT_CELL_PER_FRAME),
+                                                                  ("capacity_floor", R.STAT_CELL_CAPACITY_FLOOR))}
+        except R.RtxError:
+            pass
         mv["static_in_flight_ms_per_frame"] = round(elapsed / K * 1e3, 5)
         mv["static_alone_ms_per_frame"] = round(kernel_ms, 5)
         timing["moving_view"] = mv

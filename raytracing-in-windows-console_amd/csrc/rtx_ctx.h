@@ -90,8 +90,13 @@ struct rtx_ctx {
         bool built_on_aux = false;              // the last build ran on the side stream
         bool known_ready = false;               // the last build is known to have finished (hipEventQuery said so once)
         std::vector<hipStream_t> waited;        // streams that are already ordered after the last build
-        std::vector<hipStream_t> readers;       // streams that have queued launches reading this set since the last build
-        std::vector<hipEvent_t> reader_events;  // pool: one per reader, for ordering a rebuild after them
+        // Launches that read this set: `readers` are the streams whose latest launch read it (no event yet: recorded when the
+        // stream first reads the other set, or when this set is rebuilt, whichever comes first); `done` are events recorded
+        // right after a stream's last launch reading it.  A rebuild waits for exactly these -- not for everything the
+        // render streams have queued since, which would drain the frames in flight at every rebuild.
+        std::vector<hipStream_t> readers;
+        std::vector<hipEvent_t> done;           // in use: done[0 .. n_done)
+        size_t n_done = 0;
     };
     CellCacheSlot cell_cache[2];
     rtxplan::CellCachePolicy cell_policy;
@@ -107,6 +112,8 @@ struct rtx_ctx {
     uint64_t xcd_order_key[2] = {0, 0};
     int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
     int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
+    hipEvent_t ev_physics = nullptr;            // orders a build on the side stream after the physics steps queued so far
+    bool ns_moved_since_build = false;          // rtx_update_objects ran since the last such ordering
     uint64_t scene_gen = 1;                     // bumped by every scene edit: object counts / array addresses (recorded graphs belong to one)
     uint64_t lists_gen = 1;                     // ... and by the first physics step after one: what cell lists belong to
     bool physics_settled = false;               // every sphere has been through Sphere::Update since the last edit (|y| <= 10)

@@ -65,7 +65,6 @@ static_assert(digits_word(0) == 0x300000u && digits_word(7) == 0x370000u && digi
 // plane normals and of the hardware sqrt used below (together < 1.5e-6 |otc|).
 constexpr float kKappa = 2.0e-6f;
 constexpr float kDelta = 5.0e-6f;
-constexpr float kNearSlack = 2.0e-5f; // relative slack of the per-candidate lower bound of the hit distance (test_candidate, NEAR)
 
 struct TileFrustum {
     V3 n[5]; // inward unit normals of the four side planes, then the tile axis
@@ -368,19 +367,13 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
 // Exact tests of one ray against the candidate list (index is wave-uniform: LDS broadcast reads).
 // HOISTED: ray.divTwoA was computed before the loop (dense scenes: several candidates per pass reach the exact test, so
 // once per ray is cheaper than once per exact test; sparse scenes: 1 in 3 passes reaches none)
-// NEAR: s_near[i] is a lower bound of the hit distance of candidate i for ANY ray from the camera (staging: kNearSlack).
-// A candidate whose bound lies beyond the lane's best hit so far cannot win, nor tie (its t would be strictly larger), so
-// its exact test is skipped -- and when that holds for every lane that passed the rejection test, the whole wave skips
-// it.  Read only on the non-reject path: a pixel under a stack of k overlapping spheres runs about ln k exact tests
-// instead of k (a camera looking along the scene: up to 95 per pixel, tools/worst_view_gpu.py), everything else pays one
-// broadcast read per slow-path entry.
-template <bool HOISTED, bool NEAR>
-__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, const float* s_near, uint32_t i, Best& best, uint32_t& slow)
+template <bool HOISTED>
+__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, uint32_t i, Best& best, uint32_t& slow)
 {
     float s;
     const bool rejected = sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s);
     RTX_X_CANDIDATE_BEGIN();
-    if (!rejected && (!NEAR || !(s_near[i] > best.t))) {
+    if (!rejected) {
         if (!HOISTED) ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93; only the hit path reads it
         float t;
         if (sphere_hit(ray, s, sr.w, t)) {
@@ -394,11 +387,11 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
     }
     RTX_X_CANDIDATE_END(rejected, slow);
 }
-template <bool HOISTED, bool NEAR>
-__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, const float* s_near, uint32_t total, Best& best, uint32_t& slow)
+template <bool HOISTED>
+__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, uint32_t total, Best& best, uint32_t& slow)
 {
     for (uint32_t i = 0; i < total; i++) {
-        test_candidate<HOISTED, NEAR>(ray, s_rec[i], s_idx, s_near, i, best, slow);
+        test_candidate<HOISTED>(ray, s_rec[i], s_idx, i, best, slow);
     }
 }
 
@@ -440,13 +433,12 @@ constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes tak
 template <bool CULL>
 __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
                                                 uint32_t k0, uint32_t k1, float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8],
-                                                uint32_t parity, uint32_t total, bool drop_all, float* s_margin = nullptr, float* s_near = nullptr)
+                                                uint32_t parity, uint32_t total, bool drop_all, float* s_margin = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep[2];
     float4 rec[2];
     float mg[2] = {0.0f, 0.0f};
-    float nr[2] = {0.0f, 0.0f};
     const float4 g[2] = {g0, g1};
 
     // the second half of the step is empty when at most 256 items are left (short cell lists, the tail of a scene):
@@ -466,12 +458,6 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         const float cc = oo - (g[h].w * g[h].w);
         rec[h] = make_float4(ox, oy, oz, cc);
         keep[h] = (k < ns) && !drop_all;
-        if (s_near) {
-            // A hit at parameter t lies |d| t from the origin (|d| = 1 to 1e-7) and no nearer than |O| - r; the fp32 roots carry
-            // an absolute error below 1e-6 |O| (the cancellation in -b - sqrt(disc) at b = 2 d.O): the bound gives 2e-5 |O| away
-            // for all of that and for the hardware sqrt.  Negative for a camera inside the sphere: never skipped.
-            nr[h] = __builtin_amdgcn_sqrtf(oo) * (1.0f - kNearSlack) - fabsf(g[h].w) * (1.0f + 1.0e-6f);
-        }
         if (CULL) {
             // cc <= 0: the camera is inside or on the sphere; keep (the exact test decides)
             const bool culled = tile_culls(fr, ox, oy, oz, oo, g[h].w, mg[h]);
@@ -509,14 +495,12 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         s_rec[pos] = rec[0];
         s_idx[pos] = k0;
         if (s_margin) s_margin[pos] = mg[0];
-        if (s_near) s_near[pos] = nr[0];
     }
     if (keep[1]) {
         const uint32_t pos = total + first_total + before1 + (uint32_t)__popcll(m1 & below);
         s_rec[pos] = rec[1];
         s_idx[pos] = k1;
         if (s_margin) s_margin[pos] = mg[1];
-        if (s_near) s_near[pos] = nr[1];
     }
     return __builtin_amdgcn_readfirstlane(total + sum);
 }
@@ -566,8 +550,6 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ __attribute__((aligned(4))) uint8_t s_ramp[68]; // the glyph ramp (RayTracing.h:97-115)
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
     __shared__ float s_frustum[16];              // the macro tile's five plane normals
-    constexpr bool NEAR = CULL && !REFINE; // (the REFINE kernels' LDS has no room for it, and their scenes no stacks of spheres)
-    __shared__ float s_near[NEAR ? kListCap : 1];                           // lower bound of every list entry's hit distance
     __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
     __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
@@ -721,8 +703,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             overflow = true; // the list cannot take another step: fall back to one scene walk per sub-tile
             break;
         }
-        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u), REFINE ? s_margin : nullptr,
-                                  NEAR ? s_near : nullptr);
+        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u), REFINE ? s_margin : nullptr);
     }
     if (tid < 17u) {
         reinterpret_cast<uint32_t*>(s_ramp)[tid] = ramp4;
@@ -813,12 +794,12 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
                     for (uint32_t q = 0; q < cnt; q++) {
                         const uint32_t i = s_wlist[wave][q];
-                        test_candidate<REFINE, NEAR>(ray, s_rec[i], s_idx, s_near, i, b, slow);
+                        test_candidate<REFINE>(ray, s_rec[i], s_idx, i, b, slow);
                     }
                 }
             }
             if (!refined) {
-                if (!ABL(4u)) scan_candidates<REFINE, NEAR>(ray, s_rec, s_idx, s_near, total, b, slow);
+                if (!ABL(4u)) scan_candidates<REFINE>(ray, s_rec, s_idx, total, b, slow);
             }
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
@@ -847,10 +828,10 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 const uint32_t j0 = i0, j1 = i1;
                 h0 = load_item(its, base + kChunk + tid, i0);
                 h1 = load_item(its, base + kChunk + kThreads + tid, i1);
-                tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false, nullptr, NEAR ? s_near : nullptr);
+                tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
                     lds_barrier();
-                    scan_candidates<REFINE, NEAR>(ray, s_rec, s_idx, s_near, tot, b, slow);
+                    scan_candidates<REFINE>(ray, s_rec, s_idx, tot, b, slow);
                     tot = 0;
                 }
             }

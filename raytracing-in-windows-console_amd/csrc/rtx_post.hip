@@ -425,6 +425,7 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
     hipLaunchKernelGGL(rtx::rtx_update_spheres, dim3(blocks), dim3(rtx::kThreads), 0, ctx->stream,
                        (float4*)ctx->d_sph_geom.p, (float4*)ctx->d_sph_motion.p, ctx->ns, dt);
     RTX_HIP(ctx, hipGetLastError());
+    ctx->ns_moved_since_build = true;
     // How far a sphere can have moved (dispatch orders age with it; cell lists are valid within it: rtx_plan.hpp).  A step
     // moves a sphere by at most |speed dt| -- the clamp to [-10, 10] only shortens the move -- once it has been through one
     // step; the FIRST step after an edit may pull a sphere from anywhere onto +-10 (Sphere.cu:18-22), so it counts as

@@ -112,6 +112,8 @@ struct rtx_ctx {
     uint64_t xcd_order_key[2] = {0, 0};
     int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
     int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
+    hipStream_t recent_streams[16] = {nullptr}; // the render streams of the last two-level launches
+    unsigned recent_pos = 0, render_streams_seen = 0;
     hipEvent_t ev_physics = nullptr;            // orders a build on the side stream after the physics steps queued so far
     bool ns_moved_since_build = false;          // rtx_update_objects ran since the last such ordering
     uint64_t scene_gen = 1;                     // bumped by every scene edit: object counts / array addresses (recorded graphs belong to one)

@@ -525,8 +525,11 @@ inline CellBudget cell_motion(const CellCamera& built, const CellCamera& now)
 // Two sets of lists (double-buffered) and the rule for using, prefetching and rebuilding them.
 class CellCachePolicy {
 public:
-    static constexpr float kFramesPerBuild = 8.0f; // a budget lasts about this many frames of the current motion
+    float frames_per_build = 16.0f; // a budget lasts about this many frames of the current motion (8: lists a fifth shorter, but twice the
+                                    // rebuilds -- config 5 with a turning camera and 6 frames in flight: 52.9 us per frame against 42.5)
+    float prefetch_at = 0.5f;      // the fraction of a budget used from which the next lists are built ahead of time
     static constexpr float kCapFraction = 0.25f;   // ... but no more than this fraction of a cell's smaller angular extent
+    static constexpr float kMinFrames = 4.0f;      // ... and reuse is given up when that would last fewer frames than this
 
     enum Action {
         kUse = 0,       // the lists of slot `slot` cover this camera (slot may differ from the one used last: a finished prefetch)
@@ -567,10 +570,11 @@ public:
         last_ = cam;
         have_last_ = true;
         const float theta_cap = (float)(kCapFraction * std::fmin(cell_tan_w, cell_tan_h));
+        // ... capped; a camera that uses the cap up in fewer than kMinFrames frames is too fast for reuse to pay
         CellBudget want;
-        want.theta = kFramesPerBuild * step.theta;
-        want.delta = kFramesPerBuild * step.delta;
-        const bool too_fast = !(want.theta <= theta_cap) || !(want.delta < 1.0e29f);
+        want.theta = std::fmin(frames_per_build * step.theta, theta_cap);
+        want.delta = frames_per_build * step.delta;
+        const bool too_fast = !(kMinFrames * step.theta <= theta_cap) || !(want.delta < 1.0e29f);
 
         int best = -1;
         float best_used = 2.0f;
@@ -595,11 +599,11 @@ public:
             active_ = best;
             // more than half used and the other slot does not already hold something fresher: rebuild there, beside the frames
             const int other = best ^ 1;
-            if (best_used > 0.5f && !too_fast) {
+            if (best_used > prefetch_at && !too_fast) {
                 bool other_fresher = false;
                 if (slot_[other].valid && slot_[other].key == key) {
                     const CellBudget m = cell_motion(slot_[other].built_for, cam);
-                    other_fresher = m.theta <= 0.5f * slot_[other].budget.theta && m.delta <= 0.5f * slot_[other].budget.delta;
+                    other_fresher = m.theta <= prefetch_at * slot_[other].budget.theta && m.delta <= prefetch_at * slot_[other].budget.delta;
                 }
                 if (!other_fresher) {
                     d.prefetch = true;

@@ -403,7 +403,7 @@ static void test_cell_cache_policy()
     key.nsub = 2;
     key.ns = 65536;
     key.cap = 1280;
-    const double cw = 0.4, ch = 0.035; // a cell's extent on the view plane (config 5)
+    const double cw = 0.208, ch = 0.137; // a cell's extent on the view plane (config 5: 32 x 128 pixels)
     auto covered = [&](const CellCachePolicy& pol, const std::vector<std::pair<CellCamera, CellBudget>>& built, int slot, const CellCamera& cam) {
         (void)pol;
         const CellBudget m = cell_motion(built[(size_t)slot].first, cam);
@@ -456,7 +456,7 @@ static void test_cell_cache_policy()
         CHECK(builds <= 3);               // the start-up only (no step known yet; then the first real budget)
         CHECK(hits >= 595 && prefetches >= 600 / 10 && prefetches <= 600 / 2);
     }
-    // a camera too fast for a quarter of a cell per eight frames: per-frame binning, no cache traffic
+    // a camera too fast (a quarter of a cell in under four frames): per-frame binning, no cache traffic
     {
         CellCachePolicy pol;
         int per_frame = 0;
@@ -470,7 +470,7 @@ static void test_cell_cache_policy()
     // ... and when it comes to rest the lists are built again
     {
         CellCachePolicy pol;
-        for (int f = 0; f < 20; f++) pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch, kReady);
+        for (int f = 0; f < 20; f++) CHECK(pol.decide(key, cell_camera(3.14159265 + 0.01 * f, 0, 0, 0), cw, ch, kReady).action == CellCachePolicy::kPerFrame || f == 0);
         int builds = 0, hits = 0;
         for (int f = 0; f < 20; f++) {
             const CellCachePolicy::Decision d = pol.decide(key, cell_camera(3.14159265 + 0.2, 0, 0, 0), cw, ch, kReady);

@@ -69,8 +69,18 @@ for yaw in yaws:
         life = (s[:, 13] - s[:, 15]) / 100.0
         span = (s[:, 13].max() - s[:, 15].min()) / 100.0
         order = np.argsort(-life)[:5]
+        # per-wave features of the longest-lived workgroups (slots 8..11: estimate | slow-path entries << 20 | passes with a hit << 32 |
+        # passes << 36 | candidates scanned << 40 | exact tests that changed no lane's best hit << 52)
+        feats = []
+        for i in order[:2]:
+            for w in range(4):
+                v = int(s[i, 8 + w]) & 0xFFFFFFFFFFFFFFFF
+                feats.append("wave%d: exact-test entries %d (useless %d), candidates scanned %d, passes %d (with a hit %d)" % (
+                    w, (v >> 20) & 0xFFF, (v >> 52) & 0xFFF, (v >> 40) & 0xFFF, (v >> 36) & 0xF, (v >> 32) & 0xF))
         print("yaw pi%+.1f: %d workgroups, launch %.1f us; candidates per tile: median %d, p99 %d, max %d; tiles over 192: %d, over 704: %d; "
               "longest lifetimes (us, candidates): %s" % (yaw - math.pi, s.shape[0], span, np.median(total), np.percentile(total, 99), total.max(),
                                                            int((total > 192).sum()), int((total > 704).sum()),
                                                            [(round(float(life[i]), 1), int(total[i])) for i in order]), flush=True)
+        if yaw - math.pi > 1.35 and yaw - math.pi < 1.45 or abs(yaw - math.pi) < 0.05:
+            print("      " + "\n      ".join(feats), flush=True)
     ctx.close()

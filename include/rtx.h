@@ -101,6 +101,12 @@ enum rtx_option {
                                * always a superset of what a pixel ray of its cell can hit.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_XCD_ORDER = 9,    /* two-level grids: dispatch the macro tiles so that a cell's tiles (and neighbouring cells) run on one
                                * XCD, whose L2 then holds that part of the scene alone.  Speed only.  -1 auto (on), 0 off, 1 on */
+    RTX_OPT_VIEW_ADAPT = 10,  /* a scene that is sparse by its numbers can be locally dense from where the camera stands (config 2 seen along
+                               * its long axis: 95 candidates on one macro tile instead of 9, one launch alone 63 us instead of 27).  The
+                               * trace workgroups report their longest candidate list; when it passes 28 the following launches are
+                               * planned as for a dense scene (2 sub-tiles per workgroup, two-level culling, per-wave refinement: 23-27 us
+                               * on those views), and as before again once it has stayed short.  Same frames either way.
+                               * -1 auto (on), 0 off, 1 on */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
                                * stays off) */
@@ -114,6 +120,8 @@ enum rtx_stat {
     RTX_STAT_CELL_PER_FRAME = 104,  /* launches that binned for themselves alone (reuse off, or a fast camera) */
     RTX_STAT_ORDER_PASSES = 105,    /* dispatch-order passes queued (rtx_balance_tiles / rtx_order_tiles) */
     RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a recorded launch reads (kept as they are from then on) */
+    RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
+    RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
     RTX_STAT_CELL_CAPACITY_FLOOR = 107 /* entries per cell list the current grid is planned with at least (0: the default capacity has
                                      * sufficed); grown from the longest list the binning passes report */
 };

@@ -112,6 +112,16 @@ struct rtx_ctx {
     uint64_t xcd_order_key[2] = {0, 0};
     int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
     int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
+    // view-density feedback (rtxplan::ViewDensity): the longest candidate list the trace workgroups of an epoch (8 culling
+    // launches) report, copied to the pinned word when the epoch ends and taken as an observation once that copy has landed
+    uint32_t* d_longest = nullptr;              // two words: the epoch being filled, and the one before (being copied / zeroed)
+    volatile uint32_t* h_longest = nullptr;
+    hipEvent_t ev_longest = nullptr;
+    bool longest_copy_pending = false;
+    uint32_t longest_epoch = 0, longest_launches = 0;
+    rtxplan::ViewDensity view_density;
+    int64_t opt_view_adapt = -1;                // -1 auto (on), 0 off
+    uint64_t stat_density_switches = 0;
     hipStream_t recent_streams[16] = {nullptr}; // the render streams of the last two-level launches
     unsigned recent_pos = 0, render_streams_seen = 0;
     hipEvent_t ev_physics = nullptr;            // orders a build on the side stream after the physics steps queued so far

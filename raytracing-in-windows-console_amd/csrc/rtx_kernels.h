@@ -61,6 +61,11 @@ struct KArgs {
     // wanted).
     const uint32_t* tile_order;
     uint32_t* tile_cost;
+    // View-density feedback for the host (rtx_plan.hpp, ViewDensity), culling kernels: workgroups whose candidate list holds at
+    // least longest_from entries atomicMax its length into longest_list[longest_epoch & 1]; the first workgroup zeroes the
+    // other word, which the launches of the next epoch fill.  nullptr: no feedback.
+    uint32_t* longest_list;
+    uint32_t longest_from, longest_epoch;
     uint8_t* out;             // records of row out_row_base start here
     uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;

@@ -729,6 +729,13 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             s_nplanes = (uint32_t)__popcll(m);
         }
     }
+    // view-density feedback for the host: workgroups with a long candidate list report its length (a handful per launch in
+    // an ordinary view, none at all in most)
+    if (CULL && a.longest_list != nullptr && tid == 0u) {
+        const uint32_t len = overflow ? (uint32_t)kListCap : total;
+        if (len >= a.longest_from) atomicMax(a.longest_list + (a.longest_epoch & 1u), len);
+        if (blockIdx.x == 0u && blockIdx.y == 0u) a.longest_list[(a.longest_epoch & 1u) ^ 1u] = 0u;
+    }
     lds_barrier(); // list complete, tables visible
     const uint32_t np_vis = (uint32_t)__builtin_amdgcn_readfirstlane(s_nplanes); // planes in the table
     STAMP(2);

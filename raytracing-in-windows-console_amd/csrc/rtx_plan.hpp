@@ -94,6 +94,7 @@ struct TileRequest {
     int opt_subtiles = 0;            // RTX_OPT_SUBTILES (0 = choose)
     int opt_tile_log2w = 0;          // RTX_OPT_TILE_LOG2_W (0 = choose)
     int opt_refine = -1;             // RTX_OPT_REFINE (-1 auto)
+    bool view_dense = false;         // the launches before this one saw long candidate lists (ViewDensity): plan as for a dense scene
 };
 
 struct TileShape {
@@ -101,6 +102,7 @@ struct TileShape {
     uint32_t mw = 64, mh = 4;           // macro tile, pixels
     uint32_t grid_x = 1, grid_y = 1;    // workgroups
     bool refine = false;                // per-wave refinement kernels (dense scenes)
+    bool dense = false;                 // planned as a dense scene (by its density, or because the view is locally dense)
     uint64_t tiles256 = 0;              // 256-pixel tiles in the launch
 };
 
@@ -115,7 +117,7 @@ inline TileShape plan_tiles(const TileRequest& q)
 {
     TileShape t;
     t.tiles256 = (q.W * q.rows + 255u) / 256u;
-    const double density = (q.W && q.H) ? (double)q.ns / ((double)q.W * (double)q.H) : 0.0;
+    const double density = q.view_dense ? kDenseScene : ((q.W && q.H) ? (double)q.ns / ((double)q.W * (double)q.H) : 0.0);
     int nsub;
     if (q.opt_subtiles) {
         nsub = q.opt_subtiles;
@@ -166,6 +168,7 @@ inline TileShape plan_tiles(const TileRequest& q)
     // dense scenes: every wave narrows the workgroup's candidate list to its own 64 pixels before scanning it
     const bool want = q.opt_refine == 1 || (q.opt_refine < 0 && density >= kDenseScene);
     t.refine = q.cull && want && nsub <= 4 && t.mw <= 64u && t.mh <= 64u; // (the REFINE kernels' tables: 64 x 64)
+    t.dense = density >= kDenseScene;
     return t;
 }
 
@@ -284,6 +287,61 @@ inline uint32_t cell_capacity_wanted(uint32_t seen, uint32_t cap, uint32_t floor
     const uint32_t w = want > 0xffffffffull ? 0xffffffffu : (uint32_t)want;
     return w > floor_now ? w : floor_now;
 }
+
+// ------------------------------------------------------------------------------------------------ locally dense views
+
+// A sparse scene can look dense from where the camera stands: config 2's 1024 spheres seen along the scene's long axis put
+// 95 candidates on one 16 x 80-pixel macro tile (default view: 9 at most), and a launch alone takes as long as its slowest
+// workgroup: 63 us against 27.  The dense-scene configuration (2 sub-tiles per workgroup, two-level culling, per-wave
+// refinement) renders those views in 23-27 us but the default view in 31 (profiles/r03_i_worst_view_configs.txt).  So the
+// choice follows what the launches see: every workgroup with a long candidate list reports its length (atomicMax into a
+// word that is copied to the host once per epoch of 8 launches); past kHeavy candidates on a macro tile of the sparse plan the
+// following launches use the dense one, and return when kCalm epochs in a row saw no list of kLightDense entries on the dense
+// plan's smaller tiles.  The observation is a dozen launches old: it follows a camera that moves, it cannot follow a cut.
+class ViewDensity {
+public:
+    static constexpr uint32_t kHeavy = 28u;      // sparse plan: longest list from which the view counts as locally dense ...
+    static constexpr uint32_t kReportSparse = 12u; // ... workgroups report lists from this length on
+    static constexpr uint32_t kLightDense = 9u;  // dense plan (macro tiles 2.5 times smaller): workgroups report lists from this length
+                                                 // on, and the view counts as sparse again when kCalm epochs in a row reported none
+    static constexpr int kCalm = 3;
+
+    bool dense() const { return dense_; }
+    uint32_t report_from() const { return dense_ ? kLightDense : kReportSparse; }
+    void reset()
+    {
+        dense_ = false;
+        calm_ = 0;
+    }
+    // `longest`: the longest candidate list the launches of one epoch reported (0: none reached report_from()).  An observation
+    // made under the other plan (the copy was in flight when the plan changed) reads safely: a sparse-plan value keeps a dense
+    // plan dense, a dense-plan value is below kHeavy.  Returns true when the plan changes.
+    bool observe(uint32_t longest)
+    {
+        if (!dense_) {
+            if (longest >= kHeavy) {
+                dense_ = true;
+                calm_ = 0;
+                return true;
+            }
+            return false;
+        }
+        if (longest < kLightDense) {
+            if (++calm_ >= kCalm) {
+                dense_ = false;
+                calm_ = 0;
+                return true;
+            }
+        } else {
+            calm_ = 0;
+        }
+        return false;
+    }
+
+private:
+    bool dense_ = false;
+    int calm_ = 0;
+};
 
 // ------------------------------------------------------------------------------------------------ dispatch order
 

@@ -547,8 +547,32 @@ static void test_cell_cache_policy()
     }
 }
 
+static void test_view_density()
+{
+    ViewDensity v;
+    CHECK(!v.dense() && v.report_from() == ViewDensity::kReportSparse);
+    CHECK(!v.observe(0) && !v.observe(9) && !v.observe(27) && !v.dense());   // the default view of config 2: 9 at most
+    CHECK(v.observe(28) && v.dense() && v.report_from() == ViewDensity::kLightDense);
+    CHECK(!v.observe(95));                                                    // a sparse-plan value that was in flight: stays dense
+    CHECK(!v.observe(0) && !v.observe(0));                                    // two calm epochs are not enough ...
+    CHECK(!v.observe(12) && v.dense());                                       // ... and a long list starts the count again
+    CHECK(!v.observe(8) && !v.observe(0) && v.observe(3) && !v.dense());      // three in a row: sparse again
+    CHECK(!v.observe(8) && !v.dense());                                       // a dense-plan value that was in flight: below kHeavy
+    v.observe(40);
+    v.reset();
+    CHECK(!v.dense());
+    // the dense plan for a scene that is sparse by its numbers: 2 sub-tiles, refinement; the sparse plan is untouched by the flag's absence
+    TileRequest q = request(1920, 1080, 1080, 1025, true);
+    const TileShape sparse = plan_tiles(q);
+    q.view_dense = true;
+    const TileShape dense = plan_tiles(q);
+    CHECK(sparse.nsub == 5 && !sparse.refine && !sparse.dense);
+    CHECK(dense.nsub == 2 && dense.refine && dense.dense && dense.mw * dense.mh == 512);
+}
+
 int main()
 {
+    test_view_density();
     test_tile_shapes();
     test_cell_grid();
     test_xcd_order();

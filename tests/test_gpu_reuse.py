@@ -378,3 +378,48 @@ def test_cell_capacity_grows_with_the_longest_list_instead_of_staging_the_whole_
     finally:
         a.close()
         b.close()
+
+
+def test_plan_follows_a_view_that_turns_locally_dense(R):
+    """Config 2's scene is sparse by its numbers, but seen along its long axis one macro tile holds 95 candidates instead of 9.
+    The trace workgroups report their longest candidate list; the library then plans the following launches as for a dense
+    scene (2 sub-tiles per workgroup, two-level culling, per-wave refinement) and returns to the sparse plan when the view
+    does.  Whatever the plan: every frame equals the brute kernel's."""
+    import torch
+    p0, sph, pl = R.config_inputs("C2")
+    W, H = int(p0.x), int(p0.y)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        assert a.get_option(R.OPT_VIEW_ADAPT) == -1
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        yaws = [0.0] * 30 + [0.05 * k for k in range(1, 29)] + [1.4] * 50 + [1.4 - 0.05 * k for k in range(1, 29)] + [0.0] * 70
+        dense_at, kernels = [], set()
+        for f, dy in enumerate(yaws):
+            p = R.camera_params(W, H, pos=(0.0, 0.0, 0.0), rot=(0.0, math.pi + dy, 0.0))
+            _frame(a, p, O.RGB_ASCII, got)
+            torch.cuda.synchronize()
+            kernels.add(a.last_kernel)
+            dense_at.append(a.get_option(R.STAT_VIEW_DENSE))
+            if f % 3 == 0 or dense_at[-1] != (dense_at[-2] if f else 0):
+                _frame(b, p, O.RGB_ASCII, want)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), "frame %d (yaw +%.2f, dense plan %d)" % (f, dy, dense_at[-1])
+        assert not any(dense_at[:30])                       # the default view: sparse plan
+        assert all(dense_at[85:105])                        # looking along the scene: dense plan ...
+        assert any("refine" in k for k in kernels)          # ... with the per-wave refinement kernels
+        assert not any(dense_at[-20:])                      # and back
+        assert a.get_option(R.STAT_DENSITY_SWITCHES) >= 2
+        # switched off: the sparse plan throughout
+        a.set_option(R.OPT_VIEW_ADAPT, 0)
+        p = R.camera_params(W, H, pos=(0.0, 0.0, 0.0), rot=(0.0, math.pi + 1.4, 0.0))
+        for _ in range(40):
+            _frame(a, p, O.RGB_ASCII, got)
+        torch.cuda.synchronize()
+        assert a.get_option(R.STAT_VIEW_DENSE) == 0 and "refine" not in a.last_kernel
+        _frame(b, p, O.RGB_ASCII, want)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+    finally:
+        a.close()
+        b.close()

@@ -26,6 +26,8 @@ R = importlib.import_module("raytracing-in-windows-console_amd")
 p0, sph, pl = R.config_inputs("C2")
 W, H = int(p0.x), int(p0.y)
 yaws = [math.pi + 0.1 * k for k in range(25)]
+if any(a == "--coarse" for a in sys.argv[1:]):
+    yaws = [math.pi + 0.2 * k for k in range(13)]
 extra = [a for a in sys.argv[1:] if a.startswith("--")]
 for yaw in yaws:
     cam = R.camera_params(W, H, (0.0, 0.0, 0.0), (0.0, yaw, 0.0))
@@ -33,10 +35,17 @@ for yaw in yaws:
     ctx.set_scene(sph, pl)
     if "--two-level" in extra:
         ctx.set_option(R.OPT_TWO_LEVEL, 1)
+    for e in extra:
+        if e.startswith("--subtiles="):
+            ctx.set_option(R.OPT_SUBTILES, int(e.split("=")[1]))
+        if e.startswith("--refine="):
+            ctx.set_option(R.OPT_REFINE, int(e.split("=")[1]))
     ctx.set_option(R.OPT_TILE_ORDER, 0)       # frame order: the view's own cost, not what balancing makes of it
-    for _ in range(20):
+    if "--no-adapt" in extra:
+        ctx.set_option(R.OPT_VIEW_ADAPT, 0)
+    for _ in range(48):                        # (the plan follows what the launches see: six epochs of 8)
         ctx.render(cam, R.RGB_ASCII)
-    ctx.synchronize()
+        ctx.synchronize()
     if not stamps:
         ts = []
         for _ in range(3):

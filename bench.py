@@ -705,12 +705,19 @@ def run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, config,
                                               flags=R.RENDER_COMPACT if compact else 0)
                       for b in range(pipe.nbuf)]
 
+        # A recorded launch runs under the dispatch order its tile grid has converged to on its stream, and freezes it (rtx.h):
+        # so the first rounds are queued launch by launch until every render stream has been through the library's settling
+        # passes (about 70 launches of the slab's grid per stream), as far as the run-in allows; then the rounds are recorded.
+        settle_rounds = min(-(-72 * F // RF), max(0, prewarm_frames // RF - 2))
+        rounds_queued = [0]
+
         def render_round(q, b, nframes):
             if args.latency:
                 ev_submit[q % POOL].record(stream)
             if not rows:
                 return
-            if nframes == RF and use_graphs[0]:
+            rounds_queued[0] += 1
+            if nframes == RF and use_graphs[0] and rounds_queued[0] > settle_rounds:
                 # a full round's slab launches (forked over the render streams, joined back) as one graph replay
                 if b not in slab_graphs:
                     slab_graphs[b] = graph_or_none(lambda: submitters[b](RF), stream.cuda_stream, "slab launches")

@@ -298,11 +298,14 @@ inline uint32_t cell_capacity_wanted(uint32_t seen, uint32_t cap, uint32_t floor
 // word that is copied to the host once per epoch of 8 launches); past kHeavy candidates on a macro tile of the sparse plan the
 // following launches use the dense one, and return when kCalm epochs in a row saw no list of kLightDense entries on the dense
 // plan's smaller tiles.  The observation is a dozen launches old: it follows a camera that moves, it cannot follow a cut.
+// Longest list by yaw off the default view, sparse plan / dense plan (profiles/r03_k_candidates_by_plan.txt): 0: 9 / 9,
+// 0.2: 20 / 14, 0.4: 36 / 19, 0.6: 52 / 34, 1.0: 81 / 54, 1.4: 95 / 58 -- the plan turns dense near 0.3 rad and sparse again
+// under 0.15.
 class ViewDensity {
 public:
     static constexpr uint32_t kHeavy = 28u;      // sparse plan: longest list from which the view counts as locally dense ...
     static constexpr uint32_t kReportSparse = 12u; // ... workgroups report lists from this length on
-    static constexpr uint32_t kLightDense = 9u;  // dense plan (macro tiles 2.5 times smaller): workgroups report lists from this length
+    static constexpr uint32_t kLightDense = 12u; // dense plan (macro tiles 2.5 times smaller): workgroups report lists from this length
                                                  // on, and the view counts as sparse again when kCalm epochs in a row reported none
     static constexpr int kCalm = 3;
 
@@ -588,11 +591,13 @@ public:
     float prefetch_at = 0.5f;      // the fraction of a budget used from which the next lists are built ahead of time
     static constexpr float kCapFraction = 0.25f;   // ... but no more than this fraction of a cell's smaller angular extent
     static constexpr float kMinFrames = 4.0f;      // ... and reuse is given up when that would last fewer frames than this
+    static constexpr int kStillFrames = 2;         // still_only: launches in a row without motion before lists are built
 
     enum Action {
         kUse = 0,       // the lists of slot `slot` cover this camera (slot may differ from the one used last: a finished prefetch)
         kBuild = 1,     // none does: bin for this camera into slot `slot` with `budget`, in line, then use it
-        kPerFrame = 2   // the camera moves too fast for reuse to pay: bin per frame into the stream's own scratch, as without a cache
+        kPerFrame = 2,  // the camera moves too fast for reuse to pay: bin per frame into the stream's own scratch, as without a cache
+        kSkip = 3       // (still_only) no lists for this launch: its workgroups stage the whole scene
     };
     struct Decision {
         Action action = kPerFrame;
@@ -615,7 +620,12 @@ public:
     // ready[s]: the build of slot s has finished on the device (a slot still being built ahead of time is used only if
     // nothing finished covers the camera: switching to it at once would make every render stream wait for the build and
     // take the overlap away).
-    Decision decide(const CellKey& key, const CellCamera& cam, double cell_tan_w, double cell_tan_h, const bool ready[2])
+    //
+    // still_only: scenes too small for the pre-pass to pay frame by frame (under 2048 spheres: whole-scene staging costs a
+    // workgroup about what a pre-pass per frame costs the launch) still gain from lists that cost nothing: while the camera
+    // and the scene REST, exact lists are built once and used until something moves (config 2: 18.7 -> 17.4 us per frame
+    // in flight, 25.8 -> 24.6 alone); a launch whose camera or scene has moved since the launch before gets kSkip.
+    Decision decide(const CellKey& key, const CellCamera& cam, double cell_tan_w, double cell_tan_h, const bool ready[2], bool still_only = false)
     {
         Decision d;
         // the step from the previous frame (whatever path that one took) sets the budgets of anything built now
@@ -625,8 +635,36 @@ public:
             cam.drift >= last_.drift) {
             step = cell_motion(last_, cam);
         }
+        const bool comparable = have_last_ && last_.W == cam.W && last_.H == cam.H && last_.e1 == cam.e1 && last_.e2 == cam.e2 &&
+                                last_.scene_gen == cam.scene_gen && cam.drift >= last_.drift;
+        still_frames_ = (comparable && step.theta == 0.0f && step.delta == 0.0f) ? still_frames_ + 1 : 0;
         last_ = cam;
         have_last_ = true;
+        if (still_only) {
+            for (int s = 0; s < 2; s++) {
+                if (!slot_[s].valid || !(slot_[s].key == key)) continue;
+                const CellBudget m = cell_motion(slot_[s].built_for, cam);
+                if (m.theta == 0.0f && m.delta == 0.0f) {
+                    d.action = kUse;
+                    d.slot = s;
+                    active_ = s;
+                    return d;
+                }
+            }
+            if (still_frames_ < kStillFrames) {
+                d.action = kSkip;
+                return d;
+            }
+            d.action = kBuild;
+            d.slot = slot_[active_].valid ? (active_ ^ 1) : active_;
+            d.budget = CellBudget();
+            slot_[d.slot].valid = true;
+            slot_[d.slot].key = key;
+            slot_[d.slot].built_for = cam;
+            slot_[d.slot].budget = d.budget;
+            active_ = d.slot;
+            return d;
+        }
         const float theta_cap = (float)(kCapFraction * std::fmin(cell_tan_w, cell_tan_h));
         // ... capped; a camera that uses the cap up in fewer than kMinFrames frames is too fast for reuse to pay
         CellBudget want;
@@ -702,6 +740,7 @@ private:
     int active_ = 0;
     CellCamera last_;
     bool have_last_ = false;
+    int still_frames_ = 0;
 };
 
 } // namespace rtxplan

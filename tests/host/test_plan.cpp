@@ -527,6 +527,29 @@ static void test_cell_cache_policy()
         CHECK(plan_cells(t, 65536, q.aspect, 0, 1u << 20).cap == 65536);   // never more than the scene
         CHECK(plan_cells(t, 65536, q.aspect, 7, 4096).cap == 7);            // an explicit capacity is taken as is
     }
+    // still_only (scenes under 2048 spheres): lists only while camera and scene rest
+    {
+        CellCachePolicy pol;
+        std::vector<int> actions;
+        auto act = [&](const CellCamera& c) {
+            const CellCachePolicy::Decision d = pol.decide(key, c, cw, ch, kReady, true);
+            CHECK(!d.prefetch);
+            if (d.action == CellCachePolicy::kBuild) CHECK(d.budget.theta == 0.0f && d.budget.delta == 0.0f);
+            return (int)d.action;
+        };
+        const CellCamera rest = cell_camera(3.14159265, 0, 0, 0);
+        CHECK(act(rest) == CellCachePolicy::kSkip);    // nothing before it to compare with
+        CHECK(act(rest) == CellCachePolicy::kSkip);    // one launch without motion
+        CHECK(act(rest) == CellCachePolicy::kBuild);   // two: build exact lists
+        for (int f = 0; f < 50; f++) CHECK(act(rest) == CellCachePolicy::kUse);
+        for (int f = 1; f <= 30; f++) CHECK(act(cell_camera(3.14159265 + 1.0e-4 * f, 0, 0, 0)) == CellCachePolicy::kSkip); // moving: whole-scene staging
+        const CellCamera there = cell_camera(3.14159265 + 30.0e-4, 0, 0, 0);
+        CHECK(act(there) == CellCachePolicy::kSkip && act(there) == CellCachePolicy::kBuild && act(there) == CellCachePolicy::kUse);
+        CHECK(act(rest) == CellCachePolicy::kUse);     // back where the other set was built: still there
+        CellCamera moved_scene = rest;
+        moved_scene.drift = 0.5;                       // physics moved the spheres: the lists are not exact any more
+        CHECK(act(moved_scene) == CellCachePolicy::kSkip);
+    }
     // physics: spheres that move (drift) use the position budget like a moving camera
     {
         CellCachePolicy pol;
@@ -555,8 +578,8 @@ static void test_view_density()
     CHECK(v.observe(28) && v.dense() && v.report_from() == ViewDensity::kLightDense);
     CHECK(!v.observe(95));                                                    // a sparse-plan value that was in flight: stays dense
     CHECK(!v.observe(0) && !v.observe(0));                                    // two calm epochs are not enough ...
-    CHECK(!v.observe(12) && v.dense());                                       // ... and a long list starts the count again
-    CHECK(!v.observe(8) && !v.observe(0) && v.observe(3) && !v.dense());      // three in a row: sparse again
+    CHECK(!v.observe(14) && v.dense());                                       // ... and a long list starts the count again
+    CHECK(!v.observe(11) && !v.observe(0) && v.observe(3) && !v.dense());     // three in a row: sparse again
     CHECK(!v.observe(8) && !v.dense());                                       // a dense-plan value that was in flight: below kHeavy
     v.observe(40);
     v.reset();

@@ -190,6 +190,7 @@ def parse_args(argv=None):
     ap.add_argument("--what", default="trace", choices=["trace", "update", "update-async"],
                     help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
+    ap.add_argument("--physics", action="store_true", help="--what update: run the UpdateObjects step (dt 0.016) in every Update, as the reference does")
     ap.add_argument("--dry", action="store_true",
                     help="tests only: N>1 over gloo with CPU tensors and the CPU oracle as the renderer (no GPU, not a measurement)")
     args = ap.parse_args(argv)
@@ -363,7 +364,7 @@ def run_single(args, torch, R):
         F = 1
 
         def step(i):
-            ctx.update(params, mode)
+            ctx.update(params, mode, dt=0.016, run_physics=args.physics)
     elif args.what == "update-async":
         F = 1
         hb = [ctx.host_alloc(frame_bytes) for _ in range(2)]

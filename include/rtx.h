@@ -80,7 +80,9 @@ enum rtx_option {
     RTX_OPT_TILE_LOG2_W = 2,  /* log2 of the sub-tile width in pixels (2..6; a sub-tile is 256 pixels); 0 = choose from the camera */
     RTX_OPT_SUBTILES = 3,     /* sub-tiles per workgroup in the binned kernel (1, 2, 4, 8, 16); 0 = default */
     RTX_OPT_TWO_LEVEL = 4,    /* coarse-cell pre-pass before the binned kernel (one launch: blocks of 4x4 cells, then the cells):
-                               * -1 auto (from 2048 spheres), 0 off, 1 on (2 is accepted and means 1) */
+                               * -1 auto (from 2048 spheres; from 256 while the view is locally dense, RTX_OPT_VIEW_ADAPT; smaller
+                               * scenes get exact lists while camera and scene rest, see RTX_OPT_CELL_REUSE), 0 off, 1 on (2 is
+                               * accepted and means 1) */
     RTX_OPT_CELL_CAPACITY = 7, /* entries per coarse-cell list of that pre-pass; 0 = auto (4 * spheres / cells + 1024, so that the
                                * scratch is O(spheres)).  A cell whose list does not fit falls back to the whole scene: slower,
                                * the same frame */
@@ -94,11 +96,13 @@ enum rtx_option {
                                * ordering gains nothing and at 8K costs 10 % by separating tiles that share 128-byte lines.
                                * 0 = frame order; k > 0 = on for every grid, the order re-derived every k-th frame */
     RTX_OPT_CELL_REUSE = 8,   /* coarse-cell lists of that pre-pass outlive the frame: binned with every sphere's culling margin grown by a
-                               * motion budget (about eight frames of the camera's and the spheres' current motion), the lists serve
+                               * motion budget (about sixteen frames of the camera's and the spheres' current motion), the lists serve
                                * every later frame whose camera stays within it -- for a static view: all of them -- and are rebuilt
                                * ahead of time, beside the frames, on the library's side stream.  A camera too fast for that (a
-                               * quarter of a cell per eight frames) gets the per-frame pre-pass.  Same frames either way: a list is
-                               * always a superset of what a pixel ray of its cell can hit.  -1 auto (on), 0 off, 1 on */
+                               * quarter of a cell in under four frames) gets the per-frame pre-pass.  Scenes under 2048 spheres, for
+                               * which a pre-pass per frame does not pay, get exact lists while camera and scene rest (two launches
+                               * in a row without motion) and none otherwise.  Same frames either way: a list is always a superset
+                               * of what a pixel ray of its cell can hit.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_XCD_ORDER = 9,    /* two-level grids: dispatch the macro tiles so that a cell's tiles (and neighbouring cells) run on one
                                * XCD, whose L2 then holds that part of the scene alone.  Speed only.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_VIEW_ADAPT = 10,  /* a scene that is sparse by its numbers can be locally dense from where the camera stands (config 2 seen along

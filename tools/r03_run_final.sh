@@ -12,7 +12,7 @@ tail -3 gpurun_out/${TAG}_tests.log
 python bench.py > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err; echo "bench rc $?"
 cat gpurun_out/${TAG}_bench_c2.json
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_c2_driver_form.json 2>/dev/null; echo "driver form rc $?"
-for c in c2: c1:--config\ C1 c3:--config\ C3 c4:--config\ C4 c5:--config\ C5 update:--what\ update; do
+for c in c2: c1:--config\ C1 c3:--config\ C3 c4:--config\ C4 c5:--config\ C5 update:--what\ update\ --physics; do
   name=${c%%:*}; args=${c#*:}
   tools/profile_gpu.sh ${TAG}_$name $args > gpurun_out/${TAG}_prof_$name.log 2>&1; echo "prof $name rc $?"
 done

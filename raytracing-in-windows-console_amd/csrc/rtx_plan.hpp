@@ -111,8 +111,8 @@ constexpr double kDenseScene = 0.004; // spheres per pixel from which a scene co
 // Sub-tiles (256 pixels each) per workgroup, sub-tile shape and macro-tile layout: as square as possible on the view
 // plane, so that the culling pyramid is tight.  More sub-tiles amortise the per-workgroup set-up (tables, frustum,
 // staging) but leave fewer workgroups to fill the CUs and, with culling, lengthen the candidate lists.  Measured
-// (profiles/r01_d_subtiles.txt): brute kernel 1 / 4 / 8 at 400x150 / 1080p / 4K; binned kernel 4 at 1080p and 4K, 8 at
-// 8K, 2 for dense scenes.
+// (profiles/r01_d_subtiles.txt, r03_n): brute kernel 1 / 4 / 8 at 400x150 / 1080p / 4K; binned kernel 4 (5: one dispatch round) at
+// 1080p, 8 from 4K on, 2 for dense scenes.
 inline TileShape plan_tiles(const TileRequest& q)
 {
     TileShape t;
@@ -122,7 +122,7 @@ inline TileShape plan_tiles(const TileRequest& q)
     if (q.opt_subtiles) {
         nsub = q.opt_subtiles;
     } else if (q.cull) {
-        nsub = density >= kDenseScene ? 2 : (t.tiles256 >= 65536u ? 8 : 4);
+        nsub = density >= kDenseScene ? 2 : (t.tiles256 >= 24000u ? 8 : 4); // (config 3, 32 400 tiles: 90.3 -> 85.2 us per frame in flight with 8, alone the same)
         // One dispatch round: up to 1080p (and for the row slabs of a sharded frame) take the smallest count that lets
         // every workgroup be resident at once -- fewer, larger workgroups would leave CUs short of waves (a 135-row
         // slab: 14.0 us with 4 sub-tiles, 9.5 with 1; 270 rows: 17.1 -> 11.9 with 2), more would need a second round;
@@ -143,7 +143,10 @@ inline TileShape plan_tiles(const TileRequest& q)
     } else if (!q.cull) {
         lw = 6u; // brute: 64x4, a wave writes one contiguous row span
     } else {
-        lw = squarest_log2w(q.aspect, 256, 2, 6);
+        // (at least 8 pixels wide: a wave's row segment is then 160 bytes of records.  At 8K the reference camera's pixels are
+        // 24 : 1 and the squarest sub-tile would be 4 x 64: tightest culling, but 80-byte segments -- config 4 243 -> 207 us per
+        // frame, config 3 91.5 -> 90.0, with 8 wide)
+        lw = squarest_log2w(q.aspect, 256, 3, 6);
     }
     // macro tile of 256*nsub pixels, nx = 2^lnx sub-tiles wide and nsub/nx high, at most 128 x 128.  A sub-tile count
     // that is not a power of two is stacked vertically (nx = 1).

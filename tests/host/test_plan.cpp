@@ -56,9 +56,12 @@ static void test_tile_shapes()
     // config 5: dense -> 2 sub-tiles, per-wave refinement, macro tile within 64 x 64
     t = plan_tiles(request(1920, 1080, 1080, 65536, true));
     CHECK(t.nsub == 2 && t.refine && t.mw <= 64 && t.mh <= 64);
+    // config 3 (4K): 8 sub-tiles; sub-tiles at least 8 pixels wide whatever the pixel aspect
+    t = plan_tiles(request(3840, 2160, 2160, 4102, true));
+    CHECK(t.nsub == 8 && t.lw >= 3 && !t.refine);
     // config 4 (8K): 8 sub-tiles, several rounds
     t = plan_tiles(request(7680, 4320, 4320, 1024, true));
-    CHECK(t.nsub == 8 && (uint64_t)t.grid_x * t.grid_y > resident_slots(256));
+    CHECK(t.nsub == 8 && t.lw >= 3 && (uint64_t)t.grid_x * t.grid_y > resident_slots(256));
     // the slabs of a sharded 1080p frame: the smallest count that keeps one round
     CHECK(plan_tiles(request(1920, 1080, 540, 1025, true)).nsub == 3);
     CHECK(plan_tiles(request(1920, 1080, 270, 1025, true)).nsub == 2);

@@ -160,6 +160,7 @@ def parse_args(argv=None):
     ap.add_argument("--two-level", type=int, default=-1, help="-1 auto, 0 off, 1 on, 2 on with block binning")
     ap.add_argument("--refine", type=int, default=-1)
     ap.add_argument("--cell-reuse", type=int, default=-1, help="coarse-cell lists outlive the frame (RTX_OPT_CELL_REUSE): -1 auto (on), 0 off, 1 on")
+    ap.add_argument("--sorted-store", type=int, default=-1, help="staging reads a direction-sorted copy of the sphere array (RTX_OPT_SORTED_STORE): -1 auto (on), 0 off")
     ap.add_argument("--xcd-order", type=int, default=-1, help="XCD-aware dispatch order of two-level grids (RTX_OPT_XCD_ORDER): -1 auto, 0 off, 1 on")
     ap.add_argument("--tile-order", type=int, default=-2, help="heaviest-first dispatch of the macro tiles: -2 library default (auto), -1 auto, 0 off, k refresh period")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -335,6 +336,8 @@ def apply_options(R, ctx, args):
         ctx.set_option(R.OPT_CELL_REUSE, args.cell_reuse)
     if args.xcd_order != -1:
         ctx.set_option(R.OPT_XCD_ORDER, args.xcd_order)
+    if args.sorted_store != -1:
+        ctx.set_option(R.OPT_SORTED_STORE, args.sorted_store)
     if args.tile_order >= -1:
         ctx.set_option(R.OPT_TILE_ORDER, args.tile_order)
 

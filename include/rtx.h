@@ -111,6 +111,10 @@ enum rtx_option {
                                * planned as for a dense scene (2 sub-tiles per workgroup, two-level culling, per-wave refinement: 23-27 us
                                * on those views), and as before again once it has stayed short.  Same frames either way.
                                * -1 auto (on), 0 off, 1 on */
+    RTX_OPT_SORTED_STORE = 11,/* staging reads a copy of the sphere array sorted by direction (Morton code of azimuth and elevation as seen
+                               * from the camera of the first launch after a scene edit), kept in step by rtx_update_objects: the spheres
+                               * of a coarse cell are then neighbours in memory (config 5: a quarter of the lines per launch).  Speed
+                               * only; ties are still broken by creation order.  Scenes from 256 spheres.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
                                * stays off) */

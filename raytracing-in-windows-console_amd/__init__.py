@@ -24,7 +24,7 @@ SIZE_8BIT, SIZE_RGB = 12, 20
 
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_DEVICE, ERR_TOO_LARGE = range(7)
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
-OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER, OPT_VIEW_ADAPT = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER, OPT_VIEW_ADAPT, OPT_SORTED_STORE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN, STAT_CELL_CAPACITY_FLOOR, STAT_VIEW_DENSE, STAT_DENSITY_SWITCHES = 101, 102, 103, 104, 105, 106, 107, 108, 109
 RENDER_ZERO_TAIL = 1
 RENDER_COMPACT = 2

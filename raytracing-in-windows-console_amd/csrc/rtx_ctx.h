@@ -38,6 +38,12 @@ struct rtx_ctx {
     uint32_t ns = 0, np = 0, next_gidx = 0;
     uint32_t ns_uploaded = 0, np_uploaded = 0;
     DeviceArray d_sph_geom, d_sph_color, d_sph_od, d_sph_motion, d_pl_a, d_pl_b, d_pl_c, d_pl_od;
+    // the direction-sorted copy of the sphere array that staging reads (rtx_sort_scene): geometry by sorted position, sorted
+    // position -> sphere index, sphere index -> sorted position; valid while sorted_gen == scene_gen
+    DeviceArray d_sorted_geom, d_sorted_idx, d_pos_of;
+    std::vector<float4> h_centres;  // cx cy cz r as created, by sphere index (the sort's input; the device copy moves under physics)
+    uint64_t sorted_gen = 0;
+    int64_t opt_sorted_store = -1;  // -1 auto (on), 0 off
     std::vector<uint8_t> kind_of;   // per creation index: 1 plane, 2 sphere (Object3D.h:14)
     std::vector<uint32_t> local_of; // per creation index: index within its kind
 
@@ -175,6 +181,7 @@ int rtx_fail(rtx_ctx* ctx, int status, const std::string& msg);
 int rtx_hip_fail(rtx_ctx* ctx, hipError_t e, const char* what);
 int rtx_sync_scene(rtx_ctx* ctx);
 void rtx_scene_edited(rtx_ctx* ctx);
+int rtx_sort_scene(rtx_ctx* ctx, const float origin[3]); // rtx_post.hip
 
 #define RTX_HIP(ctx, call)                          \
     do {                                            \

@@ -508,12 +508,24 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
 // The spheres a workgroup stages: all of them (list == nullptr), or the index list its coarse cell
 // received from rtx_bin_cells (two-level culling for large scenes).
 struct Items {
-    const float4* geom;
-    const uint32_t* list; // sphere indices (any order), or nullptr
+    const float4* geom;   // the direction-sorted copy (positions), or the scene array itself (orig == nullptr)
+    const uint32_t* orig; // sorted position -> sphere index, or nullptr: positions are sphere indices
+    const uint32_t* list; // positions (any order), or nullptr: all of [0, count)
     uint32_t count;       // number of items
 };
 
-// Item i: its sphere index and geometry record.  Past the end any valid record is returned (ignored).
+__device__ __forceinline__ Items scene_items(const KArgs& a)
+{
+    Items it;
+    it.geom = a.sph_sorted_geom != nullptr ? a.sph_sorted_geom : a.sph_geom;
+    it.orig = a.sph_sorted_geom != nullptr ? a.sph_sorted_idx : nullptr;
+    it.list = nullptr;
+    it.count = a.ns;
+    return it;
+}
+
+// Item i: its sphere index (creation order: what ties are broken by and the winner's records are fetched with) and its
+// geometry record.  Past the end any valid record is returned (ignored).
 __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_t& k)
 {
     if (it.count == 0u) {
@@ -521,8 +533,9 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
         return make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const uint32_t ii = i < it.count ? i : it.count - 1u;
-    k = it.list ? it.list[ii] : ii;
-    return it.geom[k];
+    const uint32_t p = it.list ? it.list[ii] : ii;
+    k = it.orig ? it.orig[p] : p;
+    return it.geom[p];
 }
 
 constexpr int kRefineSub = 4;      // REFINE: at most this many sub-tiles (lanes 5 .. 5 + 20 per sub-tile build the pyramids)
@@ -590,10 +603,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     STAMP(0);
     RTX_X_WG_BEGIN();
     // what this workgroup stages: the whole scene, or its coarse cell's list (two-level culling)
-    Items items;
-    items.geom = a.sph_geom;
-    items.list = nullptr;
-    items.count = a.ns;
+    Items items = scene_items(a);
     if (CULL && a.cell_list != nullptr) {
         const uint32_t cell = (by >> a.cell_log2gy) * a.cells_x + (bx >> a.cell_log2gx);
         const uint32_t listed = a.cell_count[cell];
@@ -815,8 +825,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             // the item list and the pyramid, back from LDS (the compiler barrier keeps the reads in this branch instead
             // of hoisting them out of the pass loop)
             asm volatile("" ::: "memory");
-            Items its;
-            its.geom = a.sph_geom;
+            Items its = scene_items(a);
             its.list = reinterpret_cast<const uint32_t*>((uintptr_t)s_rare_ptr[0]);
             its.count = s_rare_count;
             const uint32_t nit = its.count;
@@ -1087,10 +1096,8 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
         fr.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
     }
 
-    Items items;
-    items.geom = a.sph_geom;
-    items.list = nullptr;
-    items.count = a.ns;
+    Items items = scene_items(a);
+    items.orig = nullptr; // the lists receive POSITIONS in the array staging reads (the trace workgroups map them to sphere indices)
     // this workgroup's share of the spheres: [lo, hi), a multiple of the step size except at the end
     const uint32_t ns = a.ns, splits = gridDim.y;
     const uint32_t steps = (ns + kChunk - 1) / kChunk;

@@ -4,7 +4,10 @@
 #include "rtx_ctx.h"
 #include "rtx_device.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace rtx {
 
@@ -16,7 +19,8 @@ constexpr int kSlotsPerBlock = kThreads * kItems;
 // Sphere::Update, Sphere.cu:15-23 (long double is double in device code); Plane::Update is a no-op
 // (Plane.cu:14-18).  One thread per sphere with a launch shape that is valid for any count: the
 // reference's block of `count` threads stops launching past 1024 objects.
-__global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, float4* motion, uint32_t ns, double dt)
+__global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, float4* motion, uint32_t ns, double dt, float4* sorted_geom,
+                                                               const uint32_t* pos_of)
 {
     const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= ns) {
@@ -36,6 +40,18 @@ __global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, flo
     mv.x = __uint_as_float((uint32_t)mover);
     geom[i] = g;
     motion[i] = mv;
+    if (sorted_geom != nullptr) {
+        sorted_geom[pos_of[i]] = g; // the direction-sorted copy staging reads (rtx_sort_scene) moves with it
+    }
+}
+
+// sorted[p] = geom[order[p]]: the direction-sorted copy of the sphere array, from the live one.
+__global__ __launch_bounds__(kThreads) void rtx_gather_spheres(const float4* geom, const uint32_t* order, float4* sorted, uint32_t ns)
+{
+    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
+    if (p < ns) {
+        sorted[p] = geom[order[p]];
+    }
 }
 
 // ---------------------------------------------------------------- ansi256_from_rgb over a range of inputs
@@ -422,8 +438,10 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
         if (sl.ever_built && sl.built_on_aux) RTX_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl.ev_built, 0));
     }
     const unsigned blocks = (ctx->ns + rtx::kThreads - 1) / rtx::kThreads;
+    const bool sorted = ctx->sorted_gen == ctx->scene_gen && ctx->d_sorted_geom.p != nullptr;
     hipLaunchKernelGGL(rtx::rtx_update_spheres, dim3(blocks), dim3(rtx::kThreads), 0, ctx->stream,
-                       (float4*)ctx->d_sph_geom.p, (float4*)ctx->d_sph_motion.p, ctx->ns, dt);
+                       (float4*)ctx->d_sph_geom.p, (float4*)ctx->d_sph_motion.p, ctx->ns, dt, sorted ? (float4*)ctx->d_sorted_geom.p : nullptr,
+                       sorted ? (const uint32_t*)ctx->d_pos_of.p : nullptr);
     RTX_HIP(ctx, hipGetLastError());
     ctx->ns_moved_since_build = true;
     // How far a sphere can have moved (dispatch orders age with it; cell lists are valid within it: rtx_plan.hpp).  A step
@@ -591,3 +609,75 @@ int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes)
 }
 
 } // extern "C"
+
+
+// ---- the direction-sorted copy of the sphere array (KArgs::sph_sorted_geom): spheres ordered by a Morton code of the direction
+// (azimuth, elevation) in which they lie from `origin` -- the camera's position at the first launch after a scene edit -- so that
+// the spheres of a coarse cell, or of a macro tile's pyramid, are neighbours in memory.  Host-side sort over the positions the
+// spheres were created with (physics moves them by a few units at most: the order stays good enough), then one gather on the
+// device from the live array.
+int rtx_sort_scene(rtx_ctx* ctx, const float origin[3])
+{
+    const uint32_t ns = ctx->ns;
+    if (ns == 0 || ctx->h_centres.size() != ns) return RTX_OK;
+    std::vector<uint64_t> keyed(ns);
+    std::vector<float> az(ns), el(ns);
+    float az_lo = 1e30f, az_hi = -1e30f, el_lo = 1e30f, el_hi = -1e30f;
+    for (uint32_t k = 0; k < ns; k++) {
+        const float dx = ctx->h_centres[k].x - origin[0], dy = ctx->h_centres[k].y - origin[1], dz = ctx->h_centres[k].z - origin[2];
+        const float len = std::sqrt(dx * dx + dy * dy + dz * dz);
+        float a = std::atan2(dx, dz), e = len > 0.0f ? std::asin(std::fmax(-1.0f, std::fmin(1.0f, dy / len))) : 0.0f;
+        if (!(a == a)) a = 0.0f;
+        if (!(e == e)) e = 0.0f;
+        az[k] = a;
+        el[k] = e;
+        az_lo = std::fmin(az_lo, a);
+        az_hi = std::fmax(az_hi, a);
+        el_lo = std::fmin(el_lo, e);
+        el_hi = std::fmax(el_hi, e);
+    }
+    const float sa = az_hi > az_lo ? 65535.0f / (az_hi - az_lo) : 0.0f, se = el_hi > el_lo ? 65535.0f / (el_hi - el_lo) : 0.0f;
+    auto spread = [](uint32_t x) {
+        x &= 0xffffu;
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    for (uint32_t k = 0; k < ns; k++) {
+        const uint32_t qa = (uint32_t)((az[k] - az_lo) * sa), qe = (uint32_t)((el[k] - el_lo) * se);
+        keyed[k] = ((uint64_t)(spread(qa) | (spread(qe) << 1)) << 32) | k; // (ties: creation order)
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<uint32_t> order(ns), pos_of(ns);
+    for (uint32_t p = 0; p < ns; p++) {
+        order[p] = (uint32_t)(keyed[p] & 0xffffffffu);
+        pos_of[order[p]] = p;
+    }
+    // (a scene edit: nothing may still read the old copy)
+    RTX_HIP(ctx, hipDeviceSynchronize());
+    for (DeviceArray* a : {&ctx->d_sorted_geom, &ctx->d_sorted_idx, &ctx->d_pos_of}) {
+        const size_t elem = a == &ctx->d_sorted_geom ? sizeof(float4) : sizeof(uint32_t);
+        if (a->cap < ns) {
+            if (a->p) hipFree(a->p);
+            a->p = nullptr;
+            a->cap = 0;
+            size_t cap = 1024;
+            while (cap < ns) cap *= 2;
+            if (hipMalloc(&a->p, cap * elem) != hipSuccess) {
+                (void)hipGetLastError();
+                return RTX_OK; // no sorted copy: staging reads the scene array (sorted_gen stays behind)
+            }
+            a->cap = cap;
+        }
+    }
+    RTX_HIP(ctx, hipMemcpyAsync(ctx->d_sorted_idx.p, order.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    RTX_HIP(ctx, hipMemcpyAsync(ctx->d_pos_of.p, pos_of.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(rtx::rtx_gather_spheres, dim3((ns + rtx::kThreads - 1) / rtx::kThreads), dim3(rtx::kThreads), 0, ctx->stream,
+                       (const float4*)ctx->d_sph_geom.p, (const uint32_t*)ctx->d_sorted_idx.p, (float4*)ctx->d_sorted_geom.p, ns);
+    RTX_HIP(ctx, hipGetLastError());
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (the staging vectors go out of scope; other streams may render next)
+    ctx->sorted_gen = ctx->scene_gen;
+    return RTX_OK;
+}

@@ -170,14 +170,15 @@ def test_reuse_off_and_xcd_order_off_render_the_same_frames(R):
         want = torch.empty_like(got)
         p = R.camera_params(W, H, pos=(1.0, 0.5, 0.0), rot=(0.02, math.pi + 0.1, 0.0))
         _frame(b, p, O.RGB_ASCII, want)
-        for reuse, xcd in ((0, -1), (-1, 0), (0, 0), (1, 1)):
+        for reuse, xcd, srt in ((0, -1, -1), (-1, 0, 0), (0, 0, 0), (1, 1, 1), (-1, -1, 0), (-1, -1, -1)):
             a.set_option(R.OPT_CELL_REUSE, reuse)
             a.set_option(R.OPT_XCD_ORDER, xcd)
+            a.set_option(R.OPT_SORTED_STORE, srt)   # staging from the direction-sorted copy of the sphere array, or from the array itself
             s0 = _stats(R, a)
             for _ in range(3):
                 _frame(a, p, O.RGB_ASCII, got)
                 torch.cuda.synchronize()
-                assert torch.equal(got, want), (reuse, xcd)
+                assert torch.equal(got, want), (reuse, xcd, srt)
             s1 = _stats(R, a)
             if reuse == 0:
                 assert s1["per_frame"] - s0["per_frame"] == 3 and s1["hits"] == s0["hits"]

@@ -40,7 +40,7 @@ struct rtx_ctx {
     DeviceArray d_sph_geom, d_sph_color, d_sph_od, d_sph_motion, d_pl_a, d_pl_b, d_pl_c, d_pl_od;
     // the direction-sorted copy of the sphere array that staging reads (rtx_sort_scene): geometry by sorted position, sorted
     // position -> sphere index, sphere index -> sorted position; valid while sorted_gen == scene_gen
-    DeviceArray d_sorted_geom, d_sorted_idx, d_pos_of;
+    DeviceArray d_sorted_geom, d_sorted_od, d_sorted_idx, d_pos_of;
     std::vector<float4> h_centres;  // cx cy cz r as created, by sphere index (the sort's input; the device copy moves under physics)
     uint64_t sorted_gen = 0;
     int64_t opt_sorted_store = -1;  // -1 auto (on), 0 off

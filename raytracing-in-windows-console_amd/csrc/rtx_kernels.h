@@ -35,11 +35,14 @@ struct KArgs {
     const float4* sph_od;     // R/255 G/255 B/255 gidx  (RayTracing.cu:144: colour / 255.0f, hoisted to upload time)
     // The same spheres once more in an order that keeps neighbours in direction (as seen from where the camera stood when the
     // scene was last edited) next to each other in memory: what staging reads.  A cell's ~250 spheres then sit in a few dozen
-    // 128-byte lines instead of 250 (config 5: 9.3 MB of lines per launch in creation order, 2.2 MB sorted).  sph_sorted_idx[p]
-    // is the sphere index (creation order) of sorted position p; cell lists hold sorted positions.  Both nullptr: no sorted
-    // copy, staging reads sph_geom by sphere index.
+    // 128-byte lines instead of 250 (config 5: 9.3 MB of lines per launch in creation order, 2.2 MB sorted).  With them the kernels
+    // know a sphere by its sorted position: cell lists hold positions, the winner's records are fetched by position, and only an
+    // exact tie in t looks up sph_sorted_idx[p], the sphere index (creation order) of position p.  All nullptr: no sorted copies,
+    // position = sphere index.
     const float4* sph_sorted_geom;
+    const float4* sph_sorted_od;
     const uint32_t* sph_sorted_idx;
+    const uint32_t* sph_pos_of; // sphere index -> sorted position (rtx_bin_cells walks the scene array and writes positions)
     const float4* pl_a;       // px py pz width
     const float4* pl_b;       // nx ny nz height
     const float4* pl_od;      // R/255 G/255 B/255 gidx

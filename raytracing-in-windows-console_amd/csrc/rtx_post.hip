@@ -46,11 +46,13 @@ __global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, flo
 }
 
 // sorted[p] = geom[order[p]]: the direction-sorted copy of the sphere array, from the live one.
-__global__ __launch_bounds__(kThreads) void rtx_gather_spheres(const float4* geom, const uint32_t* order, float4* sorted, uint32_t ns)
+__global__ __launch_bounds__(kThreads) void rtx_gather_spheres(const float4* geom, const float4* od, const uint32_t* order, float4* sorted_geom,
+                                                               float4* sorted_od, uint32_t ns)
 {
     const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
     if (p < ns) {
-        sorted[p] = geom[order[p]];
+        sorted_geom[p] = geom[order[p]];
+        sorted_od[p] = od[order[p]];
     }
 }
 
@@ -657,8 +659,8 @@ int rtx_sort_scene(rtx_ctx* ctx, const float origin[3])
     }
     // (a scene edit: nothing may still read the old copy)
     RTX_HIP(ctx, hipDeviceSynchronize());
-    for (DeviceArray* a : {&ctx->d_sorted_geom, &ctx->d_sorted_idx, &ctx->d_pos_of}) {
-        const size_t elem = a == &ctx->d_sorted_geom ? sizeof(float4) : sizeof(uint32_t);
+    for (DeviceArray* a : {&ctx->d_sorted_geom, &ctx->d_sorted_od, &ctx->d_sorted_idx, &ctx->d_pos_of}) {
+        const size_t elem = (a == &ctx->d_sorted_geom || a == &ctx->d_sorted_od) ? sizeof(float4) : sizeof(uint32_t);
         if (a->cap < ns) {
             if (a->p) hipFree(a->p);
             a->p = nullptr;
@@ -675,7 +677,8 @@ int rtx_sort_scene(rtx_ctx* ctx, const float origin[3])
     RTX_HIP(ctx, hipMemcpyAsync(ctx->d_sorted_idx.p, order.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     RTX_HIP(ctx, hipMemcpyAsync(ctx->d_pos_of.p, pos_of.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(rtx::rtx_gather_spheres, dim3((ns + rtx::kThreads - 1) / rtx::kThreads), dim3(rtx::kThreads), 0, ctx->stream,
-                       (const float4*)ctx->d_sph_geom.p, (const uint32_t*)ctx->d_sorted_idx.p, (float4*)ctx->d_sorted_geom.p, ns);
+                       (const float4*)ctx->d_sph_geom.p, (const float4*)ctx->d_sph_od.p, (const uint32_t*)ctx->d_sorted_idx.p,
+                       (float4*)ctx->d_sorted_geom.p, (float4*)ctx->d_sorted_od.p, ns);
     RTX_HIP(ctx, hipGetLastError());
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (the staging vectors go out of scope; other streams may render next)
     ctx->sorted_gen = ctx->scene_gen;

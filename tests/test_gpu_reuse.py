@@ -424,3 +424,38 @@ def test_plan_follows_a_view_that_turns_locally_dense(R):
     finally:
         a.close()
         b.close()
+
+
+def test_exact_ties_are_broken_by_creation_order_with_sorted_arrays(R):
+    """The kernels know a sphere by its position in the direction-sorted copies (RTX_OPT_SORTED_STORE); the reference keeps the FIRST of
+    two objects at the same distance (strict '<' in creation order, RayTracing.cu:123).  Coincident spheres of different colours --
+    created in both orders relative to their sort position -- and a plane through sphere surfaces: the frame must equal the oracle's,
+    with and without the sorted copies."""
+    import torch
+    W, H = 320, 180
+    p = R.camera_params(W, H)
+    rng = np.random.default_rng(23)
+    base, _ = R.synth_scene(31, 300, 0, p.element1, p.element2)
+    twins = base[rng.choice(300, 60, replace=False)].copy()
+    twins[:, 4:7] = np.floor(rng.uniform(1, 256, (60, 3)))          # same centre and radius, another colour: every hit is an exact tie
+    more, _ = R.synth_scene(37, 200, 0, p.element1, p.element2)
+    sph = np.concatenate([twins[:30], base, twins[30:], more, base[:10]]).astype(np.float32)   # twins created before and after their originals
+    pl = np.zeros((0, 11), dtype=np.float32)
+    sc = O.Scene.from_arrays(sph, pl)
+    want = O.render(U.oracle_params(p), sc, O.RGB_ASCII, threads=8)
+    want_bit = O.render(U.oracle_params(p), sc, O.BIT_ASCII, threads=8)
+    c = R.Context(W, H)
+    try:
+        c.set_scene(sph, pl)
+        for srt in (-1, 0, 1):
+            c.set_option(R.OPT_SORTED_STORE, srt)
+            for kernel in (R.KERNEL_AUTO, R.KERNEL_BRUTE):
+                c.set_option(R.OPT_KERNEL, kernel)
+                for two in (-1, 1):
+                    c.set_option(R.OPT_TWO_LEVEL, two)
+                    got = c.render_to_host(p, O.RGB_ASCII)
+                    assert np.array_equal(got, want), (srt, kernel, two, U.first_diff(got, want, 20, W))
+            got = c.render_to_host(p, O.BIT_ASCII)
+            assert np.array_equal(got, want_bit), srt
+    finally:
+        c.close()

@@ -31,18 +31,18 @@ struct KArgs {
     // Scene, SoA in HBM (creation order within each kind; .w of the colour arrays carries the
     // creation index across kinds as uint bits; the raw colours stay in host-visible arrays of the
     // context for rtx_scene_get_object):
+    // What the TRACE kernels read, by position: the direction-sorted copies when there are some (scenes from 256 spheres,
+    // RTX_OPT_SORTED_STORE) -- spheres ordered by a Morton code of the direction in which they lie from where the camera stood when
+    // the scene was last edited, so that a cell's ~250 spheres sit in a few dozen 128-byte lines instead of 250 (config 5: 9.3 MB
+    // of lines per launch in creation order, 2.2 MB sorted) -- else the scene arrays themselves, where position = sphere index.
+    // Cell lists hold positions, candidates carry positions, the winner's records are fetched by position.
     const float4* sph_geom;   // cx cy cz r
     const float4* sph_od;     // R/255 G/255 B/255 gidx  (RayTracing.cu:144: colour / 255.0f, hoisted to upload time)
-    // The same spheres once more in an order that keeps neighbours in direction (as seen from where the camera stood when the
-    // scene was last edited) next to each other in memory: what staging reads.  A cell's ~250 spheres then sit in a few dozen
-    // 128-byte lines instead of 250 (config 5: 9.3 MB of lines per launch in creation order, 2.2 MB sorted).  With them the kernels
-    // know a sphere by its sorted position: cell lists hold positions, the winner's records are fetched by position, and only an
-    // exact tie in t looks up sph_sorted_idx[p], the sphere index (creation order) of position p.  All nullptr: no sorted copies,
-    // position = sphere index.
-    const float4* sph_sorted_geom;
-    const float4* sph_sorted_od;
-    const uint32_t* sph_sorted_idx;
-    const uint32_t* sph_pos_of; // sphere index -> sorted position (rtx_bin_cells walks the scene array and writes positions)
+    const uint32_t* sph_sorted_idx; // position -> sphere index (creation order), looked up only to break an exact tie in t; nullptr: identity
+    // What rtx_bin_cells reads: the scene array in creation order (in the sorted copy a block's spheres fall into one workgroup's
+    // share), and the translation it writes the lists through (nullptr: identity).
+    const float4* sph_scene_geom;
+    const uint32_t* sph_pos_of;
     const float4* pl_a;       // px py pz width
     const float4* pl_b;       // nx ny nz height
     const float4* pl_od;      // R/255 G/255 B/255 gidx

@@ -232,9 +232,13 @@ struct Best {
 };
 
 // Does the sphere at position p come before the one at position q in creation order?  (The reference keeps the first of two
-// objects at the same distance, RayTracing.cu:123; q = 0xffffffff: no sphere yet.)  Rare path: two loads when the arrays are sorted.
-__device__ __forceinline__ bool comes_first(const uint32_t* __restrict__ sorted_idx, uint32_t p, uint32_t q)
+// objects at the same distance, RayTracing.cu:123; q = 0xffffffff: no sphere yet.)  Rare path: the translation table's address
+// is parked in LDS (rare[kRareSortedIdx]; 0 = positions are sphere indices), two loads when the arrays are sorted.
+constexpr int kRareSortedIdx = 4;
+__device__ __forceinline__ bool comes_first(const unsigned long long* rare, uint32_t p, uint32_t q)
 {
+    asm volatile("" ::: "memory"); // (keeps the read below in this branch instead of hoisting it out of the candidate loop)
+    const uint32_t* sorted_idx = reinterpret_cast<const uint32_t*>((uintptr_t)rare[kRareSortedIdx]);
     if (q == 0xffffffffu || sorted_idx == nullptr) {
         return p < q;
     }
@@ -378,7 +382,7 @@ __device__ __forceinline__ void encode_and_store(const KArgs& a, const Camera& c
 // HOISTED: ray.divTwoA was computed before the loop (dense scenes: several candidates per pass reach the exact test, so
 // once per ray is cheaper than once per exact test; sparse scenes: 1 in 3 passes reaches none)
 template <bool HOISTED>
-__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, const uint32_t* sorted_idx, uint32_t i, Best& best, uint32_t& slow)
+__device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const uint32_t* s_idx, const unsigned long long* rare, uint32_t i, Best& best, uint32_t& slow)
 {
     float s;
     const bool rejected = sphere_reject(ray, sr.x, sr.y, sr.z, sr.w, s);
@@ -388,7 +392,7 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
         float t;
         if (sphere_hit(ray, s, sr.w, t)) {
             const uint32_t ki = s_idx[i];
-            if (t < best.t || (t == best.t && comes_first(sorted_idx, ki, best.k))) {
+            if (t < best.t || (t == best.t && comes_first(rare, ki, best.k))) {
                 best.t = t;
                 best.k = ki;
                 RTX_X_CANDIDATE_UPDATED();
@@ -398,11 +402,11 @@ __device__ __forceinline__ void test_candidate(Ray& ray, const float4 sr, const 
     RTX_X_CANDIDATE_END(rejected, slow);
 }
 template <bool HOISTED>
-__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, const uint32_t* sorted_idx, uint32_t total, Best& best,
+__device__ __forceinline__ void scan_candidates(Ray& ray, const float4* s_rec, const uint32_t* s_idx, const unsigned long long* rare, uint32_t total, Best& best,
                                                 uint32_t& slow)
 {
     for (uint32_t i = 0; i < total; i++) {
-        test_candidate<HOISTED>(ray, s_rec[i], s_idx, sorted_idx, i, best, slow);
+        test_candidate<HOISTED>(ray, s_rec[i], s_idx, rare, i, best, slow);
     }
 }
 
@@ -530,7 +534,7 @@ struct Items {
 __device__ __forceinline__ Items scene_items(const KArgs& a)
 {
     Items it;
-    it.geom = a.sph_sorted_geom != nullptr ? a.sph_sorted_geom : a.sph_geom;
+    it.geom = a.sph_geom;
     it.list = nullptr;
     it.count = a.ns;
     return it;
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // What only the rare paths of the pass loop need (the overflow fallback: the item list and the pyramid; planes
     // beyond the table: the plane arrays) is parked here and read back inside those paths, so that it does not
     // occupy scalar registers -- or spill slots that every pass reloads -- for the whole loop.
-    __shared__ unsigned long long s_rare_ptr[4]; // item list, pl_a, pl_b, pl_od
+    __shared__ unsigned long long s_rare_ptr[5]; // item list, pl_a, pl_b, pl_od, sorted position -> sphere index (ties)
     __shared__ uint32_t s_rare_count;            // items
 
     const uint32_t tid = threadIdx.x;
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         s_rare_ptr[1] = (unsigned long long)(uintptr_t)a.pl_a;
         s_rare_ptr[2] = (unsigned long long)(uintptr_t)a.pl_b;
         s_rare_ptr[3] = (unsigned long long)(uintptr_t)a.pl_od;
+        s_rare_ptr[kRareSortedIdx] = (unsigned long long)(uintptr_t)a.sph_sorted_idx;
         s_rare_count = items.count;
     }
     // first staging step's loads go out before anything else
@@ -821,12 +826,12 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
                     for (uint32_t q = 0; q < cnt; q++) {
                         const uint32_t i = s_wlist[wave][q];
-                        test_candidate<REFINE>(ray, s_rec[i], s_idx, a.sph_sorted_idx, i, b, slow);
+                        test_candidate<REFINE>(ray, s_rec[i], s_idx, s_rare_ptr, i, b, slow);
                     }
                 }
             }
             if (!refined) {
-                if (!ABL(4u)) scan_candidates<REFINE>(ray, s_rec, s_idx, a.sph_sorted_idx, total, b, slow);
+                if (!ABL(4u)) scan_candidates<REFINE>(ray, s_rec, s_idx, s_rare_ptr, total, b, slow);
             }
         } else {
             // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
@@ -857,7 +862,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
                 if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
                     lds_barrier();
-                    scan_candidates<REFINE>(ray, s_rec, s_idx, a.sph_sorted_idx, tot, b, slow);
+                    scan_candidates<REFINE>(ray, s_rec, s_idx, s_rare_ptr, tot, b, slow);
                     tot = 0;
                 }
             }
@@ -868,8 +873,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         uint32_t best_gidx = 0xffffffffu;
         float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wod = wgeom;
         if (b.k != 0xffffffffu) { // (by position: the arrays staging read, whose lines are in this XCD's L2 already)
-            wgeom = (a.sph_sorted_geom != nullptr ? a.sph_sorted_geom : a.sph_geom)[b.k];
-            wod = (a.sph_sorted_od != nullptr ? a.sph_sorted_od : a.sph_od)[b.k];
+            wgeom = a.sph_geom[b.k];
+            wod = a.sph_od[b.k];
         }
         const bool sphere_hit_any = b.k != 0xffffffffu;
 
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
     // The pass walks the scene array in creation order -- in the direction-sorted copy a block's spheres sit in one stretch, i.e.
     // in one workgroup's share: 36 us instead of 18 -- and translates the survivors to positions when it writes the lists.
     Items items;
-    items.geom = a.sph_geom;
+    items.geom = a.sph_scene_geom;
     items.list = nullptr;
     items.count = a.ns;
     // this workgroup's share of the spheres: [lo, hi), a multiple of the step size except at the end

@@ -613,7 +613,7 @@ int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes)
 } // extern "C"
 
 
-// ---- the direction-sorted copy of the sphere array (KArgs::sph_sorted_geom): spheres ordered by a Morton code of the direction
+// ---- the direction-sorted copy of the sphere array (what KArgs::sph_geom and sph_od point at for the trace kernels): spheres ordered by a Morton code of the direction
 // (azimuth, elevation) in which they lie from `origin` -- the camera's position at the first launch after a scene edit -- so that
 // the spheres of a coarse cell, or of a macro tile's pyramid, are neighbours in memory.  Host-side sort over the positions the
 // spheres were created with (physics moves them by a few units at most: the order stays good enough), then one gather on the

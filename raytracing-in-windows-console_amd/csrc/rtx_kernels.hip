@@ -1,19 +1,20 @@
 // rtx_kernels.hip -- gfx950 kernels of the ray-trace hot path.
 //
-// One thread per pixel per pass (as the reference, RayTracingManager.cu:120-125).  A 256-thread
-// workgroup owns a macro tile of NSUB sub-tiles, each 2^lw x 2^(8-lw) pixels, and handles one
-// sub-tile per pass.  Once per workgroup: the sphere array is walked in chunks of 256 (coalesced
-// float4 loads), the ray-independent terms otc = o - c and cc = Dot(otc,otc) - r*r are hoisted
-// (Sphere.cu:34-37), spheres whose inflated bound cannot touch the macro tile's pyramid are
-// culled (CULL), and survivors are appended in index order to a candidate list in LDS; the
-// per-column and per-row terms of ray generation and the decimal-digit table are staged in LDS
-// as well.  Then, per sub-tile, every thread runs the reference's exact ray/sphere test over the
-// list (wave-uniform index, LDS broadcast reads); planes are tested from scalar loads.  The
-// winner alone is shaded and encoded (the reference re-derives normal/colour on every improving
-// hit, RayTracing.cu:123-135, but only the last survives).
+// One thread per pixel per pass (as the reference, RayTracingManager.cu:120-125).  A 256-thread workgroup owns a macro tile
+// of NSUB sub-tiles, each 2^lw x 2^(8-lw) pixels, and handles one sub-tile per pass.  Once per workgroup: the spheres it has
+// to consider -- the whole scene, or the list of its coarse cell (rtx_bin_cells; lists may outlive the frame, rtx_plan.hpp) --
+// are walked 512 at a time (two coalesced float4 loads per thread, the next step prefetched), the ray-independent terms
+// otc = o - c and cc = Dot(otc,otc) - r*r are hoisted (Sphere.cu:34-37), spheres whose inflated bound cannot touch the macro
+// tile's pyramid are culled (CULL), and survivors are appended to a candidate list in LDS; the per-column and per-row terms
+// of ray generation, the decimal-digit table, the glyph ramp and the planes the tile can see are staged in LDS as well.
+// Then, per sub-tile, every thread runs the reference's exact ray/sphere test over the list (wave-uniform index, LDS broadcast
+// reads; REFINE: over the part of it that can touch the wave's own 64 pixels) and the plane tests from the LDS table.  The
+// winner alone is shaded and encoded (the reference re-derives normal/colour on every improving hit, RayTracing.cu:123-135,
+// but only the last survives).
 //
-// Closest hit = lexicographic minimum of (t, creation index): the same object the reference's
-// in-order scan with strict '<' keeps (RayTracing.cu:123).
+// Closest hit = lexicographic minimum of (t, creation order): the same object the reference's in-order scan with strict '<'
+// keeps (RayTracing.cu:123).  Spheres are known by their position in the arrays the kernel reads (KArgs::sph_geom: the
+// direction-sorted copies when there are some); the creation order is looked up only in an exact tie (comes_first).
 #include "rtx_device.hpp"
 #include "rtx_kernels.h"
 

@@ -10,6 +10,7 @@
 // grid) and fills in the culling the reference only sketches in comments (RayTracingManager.cu:21-24, 109-117).
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -289,6 +290,52 @@ inline uint32_t cell_capacity_wanted(uint32_t seen, uint32_t cap, uint32_t floor
     const uint64_t want = ((uint64_t)seen * 3u / 2u + 64u + 255u) / 256u * 256u;
     const uint32_t w = want > 0xffffffffull ? 0xffffffffu : (uint32_t)want;
     return w > floor_now ? w : floor_now;
+}
+
+// ------------------------------------------------------------------------------------------------ direction order
+
+// The order of the direction-sorted copies of the sphere arrays (KArgs::sph_geom for the trace kernels): positions by a Morton
+// code of the direction -- azimuth atan2(dx, dz), elevation asin(dy / |d|), 16 bits each over their range -- in which a sphere's
+// centre lies from `origin`; equal codes keep creation order.  centres: x y z (stride `stride` floats).  order[p] = sphere index
+// at position p, pos_of[k] = position of sphere k.  NaN / zero-length directions sort as direction (0, 0).
+inline void direction_order(const float* centres, size_t stride, uint32_t n, const float origin[3], std::vector<uint32_t>& order, std::vector<uint32_t>& pos_of)
+{
+    std::vector<float> az(n), el(n);
+    float az_lo = 1e30f, az_hi = -1e30f, el_lo = 1e30f, el_hi = -1e30f;
+    for (uint32_t k = 0; k < n; k++) {
+        const float dx = centres[k * stride + 0] - origin[0], dy = centres[k * stride + 1] - origin[1], dz = centres[k * stride + 2] - origin[2];
+        const float len = std::sqrt(dx * dx + dy * dy + dz * dz);
+        float a = std::atan2(dx, dz), e = len > 0.0f ? std::asin(std::fmax(-1.0f, std::fmin(1.0f, dy / len))) : 0.0f;
+        if (!(a == a)) a = 0.0f;
+        if (!(e == e)) e = 0.0f;
+        az[k] = a;
+        el[k] = e;
+        az_lo = std::fmin(az_lo, a);
+        az_hi = std::fmax(az_hi, a);
+        el_lo = std::fmin(el_lo, e);
+        el_hi = std::fmax(el_hi, e);
+    }
+    const float sa = az_hi > az_lo ? 65535.0f / (az_hi - az_lo) : 0.0f, se = el_hi > el_lo ? 65535.0f / (el_hi - el_lo) : 0.0f;
+    auto spread = [](uint32_t x) {
+        x &= 0xffffu;
+        x = (x | (x << 8)) & 0x00ff00ffu;
+        x = (x | (x << 4)) & 0x0f0f0f0fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        return x;
+    };
+    std::vector<uint64_t> keyed(n);
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t qa = (uint32_t)((az[k] - az_lo) * sa), qe = (uint32_t)((el[k] - el_lo) * se);
+        keyed[k] = ((uint64_t)(spread(qa) | (spread(qe) << 1)) << 32) | k;
+    }
+    std::sort(keyed.begin(), keyed.end());
+    order.resize(n);
+    pos_of.resize(n);
+    for (uint32_t p = 0; p < n; p++) {
+        order[p] = (uint32_t)(keyed[p] & 0xffffffffu);
+        pos_of[order[p]] = p;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ locally dense views

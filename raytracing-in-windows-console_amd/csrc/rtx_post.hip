@@ -615,48 +615,15 @@ int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes)
 
 // ---- the direction-sorted copy of the sphere array (what KArgs::sph_geom and sph_od point at for the trace kernels): spheres ordered by a Morton code of the direction
 // (azimuth, elevation) in which they lie from `origin` -- the camera's position at the first launch after a scene edit -- so that
-// the spheres of a coarse cell, or of a macro tile's pyramid, are neighbours in memory.  Host-side sort over the positions the
-// spheres were created with (physics moves them by a few units at most: the order stays good enough), then one gather on the
-// device from the live array.
+// the spheres of a coarse cell, or of a macro tile's pyramid, are neighbours in memory.  Host-side sort (rtxplan::direction_order)
+// over the positions the spheres were created with (physics moves them by a few units at most: the order stays good enough),
+// then one gather on the device from the live arrays.
 int rtx_sort_scene(rtx_ctx* ctx, const float origin[3])
 {
     const uint32_t ns = ctx->ns;
     if (ns == 0 || ctx->h_centres.size() != ns) return RTX_OK;
-    std::vector<uint64_t> keyed(ns);
-    std::vector<float> az(ns), el(ns);
-    float az_lo = 1e30f, az_hi = -1e30f, el_lo = 1e30f, el_hi = -1e30f;
-    for (uint32_t k = 0; k < ns; k++) {
-        const float dx = ctx->h_centres[k].x - origin[0], dy = ctx->h_centres[k].y - origin[1], dz = ctx->h_centres[k].z - origin[2];
-        const float len = std::sqrt(dx * dx + dy * dy + dz * dz);
-        float a = std::atan2(dx, dz), e = len > 0.0f ? std::asin(std::fmax(-1.0f, std::fmin(1.0f, dy / len))) : 0.0f;
-        if (!(a == a)) a = 0.0f;
-        if (!(e == e)) e = 0.0f;
-        az[k] = a;
-        el[k] = e;
-        az_lo = std::fmin(az_lo, a);
-        az_hi = std::fmax(az_hi, a);
-        el_lo = std::fmin(el_lo, e);
-        el_hi = std::fmax(el_hi, e);
-    }
-    const float sa = az_hi > az_lo ? 65535.0f / (az_hi - az_lo) : 0.0f, se = el_hi > el_lo ? 65535.0f / (el_hi - el_lo) : 0.0f;
-    auto spread = [](uint32_t x) {
-        x &= 0xffffu;
-        x = (x | (x << 8)) & 0x00ff00ffu;
-        x = (x | (x << 4)) & 0x0f0f0f0fu;
-        x = (x | (x << 2)) & 0x33333333u;
-        x = (x | (x << 1)) & 0x55555555u;
-        return x;
-    };
-    for (uint32_t k = 0; k < ns; k++) {
-        const uint32_t qa = (uint32_t)((az[k] - az_lo) * sa), qe = (uint32_t)((el[k] - el_lo) * se);
-        keyed[k] = ((uint64_t)(spread(qa) | (spread(qe) << 1)) << 32) | k; // (ties: creation order)
-    }
-    std::sort(keyed.begin(), keyed.end());
-    std::vector<uint32_t> order(ns), pos_of(ns);
-    for (uint32_t p = 0; p < ns; p++) {
-        order[p] = (uint32_t)(keyed[p] & 0xffffffffu);
-        pos_of[order[p]] = p;
-    }
+    std::vector<uint32_t> order, pos_of;
+    rtxplan::direction_order(&ctx->h_centres[0].x, sizeof(float4) / sizeof(float), ns, origin, order, pos_of);
     // (a scene edit: nothing may still read the old copy)
     RTX_HIP(ctx, hipDeviceSynchronize());
     for (DeviceArray* a : {&ctx->d_sorted_geom, &ctx->d_sorted_od, &ctx->d_sorted_idx, &ctx->d_pos_of}) {

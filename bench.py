@@ -987,6 +987,8 @@ def main(argv=None):
         # no launcher around us: be the launcher (a parent that never touches the GPU)
         return self_launch(args, argv)
 
+    # dmabuf IPC (RCCL across processes needs it on this driver); before anything initialises HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -21,6 +21,10 @@ struct KArgs {
     float ox, oy, oz;     // camPos
     float e1, e2, far;    // element1, element2, camFarDist
     float fW, fH;         // (float)W, (float)H
+    // the culling pyramids' side planes (rtx_plan.hpp, EdgeBasis): n_row(cy) = cy P + Qr, n_col(cx) = -cx P + Qc, and the
+    // squared lengths |P|^2, |Qr|^2, |Qc|^2 of the refusal test
+    float edge_p[3], edge_qr[3], edge_qc[3];
+    float edge_pp, edge_qrqr, edge_qcqc;
     uint32_t W, H;
     uint32_t row0, row_end;   // rows traced by this launch (global row indices)
     uint32_t out_row_base;    // the row stored at out[0]

@@ -122,32 +122,43 @@ __device__ __forceinline__ bool tile_culls_moving(const TileFrustum& f, float ox
 
 // One plane of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows [row0, row0+h), grown by
 // half a pixel on every side, selected by k: 0..3 the side through corners k and k+1 (corner order (x0,y0) (x1,y0)
-// (x1,y1) (x0,y1)), 4 the axis plane -- arranged so that five lanes compute the five planes side by side.  Pixel
-// directions are linear in (cx, cy), so every pixel ray of the rectangle lies in the convex cone of the four corner
-// directions.  A normal that cannot be oriented (degenerate matrix, NaN) becomes the zero vector, which never
-// culls.  This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the slack in
-// tile_culls covers their error.
-__device__ __forceinline__ V3 tile_plane(const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, uint32_t k)
+// (x1,y1) (x0,y1): k = 0 the row edge y0, 1 the column edge x1, 2 the row edge y1, 3 the column edge x0), 4 the axis plane --
+// arranged so that five lanes compute the five planes side by side.  Pixel directions are linear in (cx, cy), so every
+// pixel ray of the rectangle lies in the convex cone of the four corner directions, and the plane through the apex and an
+// edge cy = y (cx = x) has the normal y P + Qr (-x P + Qc) with three per-frame vectors (rtx_plan.hpp, EdgeBasis: computed
+// on the host in double).  NOT the cross product of the two corner directions: for a thin tile far off the view axis those
+// are nearly parallel and long, and the fp32 product loses the plane (8K, turned camera: up to 7e-4 rad, pixels lost).
+// A normal that cannot be oriented or is ill-conditioned (degenerate or sheared matrix, NaN) becomes the zero vector,
+// which never culls.  This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the
+// slack in tile_culls covers their error and the normal's (4e-7 from the two roundings per component and the rounded
+// P, Q; 4e-7 from the edge coordinate's own rounding).
+__device__ __forceinline__ V3 tile_plane(const KArgs& a, const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, uint32_t k)
 {
     const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
     const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
     const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
     const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;
     const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;
-    const uint32_t ka = k & 3u, kb = (k + 1u) & 3u;
-    const float xa = (ka == 1u || ka == 2u) ? x1 : x0, ya = ka >= 2u ? y1 : y0;
-    const float xb = (kb == 1u || kb == 2u) ? x1 : x0, yb = kb >= 2u ? y1 : y0;
-    const V3 va = view_dir(c, xa, ya), vb = view_dir(c, xb, yb);
     const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
-    V3 n = k < 4u ? cross(va, vb) : axis;
+    V3 n = axis;
     if (k == 4u) {
         // The axis plane (it culls what lies behind the apex) is only a bound while every ray of the pyramid points
         // into its front half-space, i.e. while all four corner directions do: a wide rectangle that straddles the
         // view axis off-centre (a block of cells hanging over the frame's edge, a tile of a 5-pixel-wide frame) has
         // corner rays more than 90 degrees from its own axis.  Then the plane is dropped (zero normal: never culls).
-        const V3 vc = view_dir(c, x1, y1), vd = view_dir(c, x0, y1); // va, vb are corners 0 and 1 here
+        const V3 va = view_dir(c, x0, y0), vb = view_dir(c, x1, y0), vc = view_dir(c, x1, y1), vd = view_dir(c, x0, y1);
         const float lo = fminf(fminf(dot(va, axis), dot(vb, axis)), fminf(dot(vc, axis), dot(vd, axis)));
         if (!(lo > 0.0f)) {
+            return v3(0.0f, 0.0f, 0.0f);
+        }
+    } else {
+        const bool row_edge = (k & 1u) == 0u;
+        const float t = row_edge ? (k == 0u ? y0 : y1) : (k == 1u ? -x1 : -x0);
+        const V3 q = row_edge ? v3(a.edge_qr[0], a.edge_qr[1], a.edge_qr[2]) : v3(a.edge_qc[0], a.edge_qc[1], a.edge_qc[2]);
+        n = v3(t * a.edge_p[0] + q.x, t * a.edge_p[1] + q.y, t * a.edge_p[2] + q.z);
+        // refuse a sum that cancelled (the two terms are perpendicular for a camera matrix: no cancellation at all)
+        const float hyp2 = (t * t) * a.edge_pp + (row_edge ? a.edge_qrqr : a.edge_qcqc);
+        if (!(dot(n, n) >= 0.25f * hyp2)) {
             return v3(0.0f, 0.0f, 0.0f);
         }
     }
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 pw = tw;
                 ph = 64u >> lw;
             }
-            const V3 n = tile_plane(cam, pc0, pr0, pw, ph, pk);
+            const V3 n = tile_plane(a, cam, pc0, pr0, pw, ph, pk);
             if (tid < 5u) {
                 s_frustum[3 * tid + 0] = n.x;
                 s_frustum[3 * tid + 1] = n.y;
@@ -1083,14 +1094,14 @@ __global__ __launch_bounds__(kThreads) void rtx_bin_cells(const KArgs a)
     // pyramids: lanes 0..4 the block's five planes, lanes 5..84 plane k of cell c = (lane - 5) / 5
     if (tid < 5u + 5u * (uint32_t)kBlockCells) {
         if (tid < 5u) {
-            const V3 n = tile_plane(cam, bbx * 4u * cw, a.row0 + bby * 4u * ch, 4u * cw, 4u * ch, tid);
+            const V3 n = tile_plane(a, cam, bbx * 4u * cw, a.row0 + bby * 4u * ch, 4u * cw, 4u * ch, tid);
             s_frustum[3 * tid + 0] = n.x;
             s_frustum[3 * tid + 1] = n.y;
             s_frustum[3 * tid + 2] = n.z;
         } else {
             const uint32_t q = tid - 5u, c = q / 5u, k = q - c * 5u;
             const uint32_t cx = bbx * 4u + (c & 3u), cy = bby * 4u + (c >> 2);
-            const V3 n = tile_plane(cam, cx * cw, a.row0 + cy * ch, cw, ch, k);
+            const V3 n = tile_plane(a, cam, cx * cw, a.row0 + cy * ch, cw, ch, k);
             s_cellfr[c][k] = make_float4(n.x, n.y, n.z, 0.0f);
         }
     }

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -72,6 +73,59 @@ inline bool pixel_steps(const float inv_v[16], float e1, float e2, uint64_t W, u
         return false;
     }
     return true;
+}
+
+// The culling pyramids' side planes, well conditioned.  A pixel direction is linear in the view-plane point (cx, cy):
+//   w(cx, cy) = A cx + B cy + C,   A = e1 (m0, m4, m8),  B = e2 (m1, m5, m9),  C = (m2, m6, m10).
+// The plane through the apex and a ROW edge cy = y (all cx) has normal w(x0, y) x w(x1, y) = (x0 - x1) A x (B y + C), the plane
+// through a COLUMN edge cx = x has normal (y0 - y1) B x (A x + C):
+//   n_row(y) = y P + Qr,   n_col(x) = -x P + Qc,   P = A x B,  Qr = A x C,  Qc = B x C
+// (orientation is the caller's business).  The kernels used to take the cross product of the two corner DIRECTIONS in fp32;
+// at 8K the reference's horizontal tangent extent is 25 (element1 = 0.577 H / 100), a 16-column tile at the frame's edge
+// spans 1.7e-4 rad, and that cross product of two nearly parallel vectors of length 25 carries a direction error of up to
+// 7e-4 rad -- a hundred times the half pixel the pyramid is grown by: culling kernels lost pixels against the brute kernel
+// for turned cameras at 7680 x 4320 (tools/wide_view_cull_gpu.py).  P, Qr, Qc are cross products of (for a camera matrix)
+// perpendicular vectors, computed here in double from the fp32 parameters and rounded once; on the device one multiply-add per
+// component gives the normal to ~4e-7 whatever the tile's size.  pp, qrqr, qcqc are the squared lengths the device uses to
+// refuse an ill-conditioned sum (a sheared matrix: |y P + Qr|^2 < (y^2 |P|^2 + |Qr|^2) / 4 -> the plane never culls).
+struct EdgeBasis {
+    float p[3] = {0, 0, 0}, qr[3] = {0, 0, 0}, qc[3] = {0, 0, 0};
+    float pp = 0, qrqr = 0, qcqc = 0;
+};
+
+inline EdgeBasis edge_basis(const float inv_v[16], float e1, float e2)
+{
+    const float* m = inv_v;
+    const double A[3] = {(double)e1 * m[0], (double)e1 * m[4], (double)e1 * m[8]};
+    const double B[3] = {(double)e2 * m[1], (double)e2 * m[5], (double)e2 * m[9]};
+    const double C[3] = {(double)m[2], (double)m[6], (double)m[10]};
+    auto cross = [](const double* a, const double* b, double* o) {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    double P[3], Qr[3], Qc[3];
+    cross(A, B, P);
+    cross(A, C, Qr);
+    cross(B, C, Qc);
+    EdgeBasis e;
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+        e.p[k] = (float)P[k];
+        e.qr[k] = (float)Qr[k];
+        e.qc[k] = (float)Qc[k];
+        ok = ok && std::isfinite(e.p[k]) && std::isfinite(e.qr[k]) && std::isfinite(e.qc[k]);
+    }
+    // squared lengths, rounded UP a little: they only feed the refusal test, which must not be passed by rounding
+    e.pp = (float)((P[0] * P[0] + P[1] * P[1] + P[2] * P[2]) * (1.0 + 1e-6));
+    e.qrqr = (float)((Qr[0] * Qr[0] + Qr[1] * Qr[1] + Qr[2] * Qr[2]) * (1.0 + 1e-6));
+    e.qcqc = (float)((Qc[0] * Qc[0] + Qc[1] * Qc[1] + Qc[2] * Qc[2]) * (1.0 + 1e-6));
+    if (!ok || !std::isfinite(e.pp) || !std::isfinite(e.qrqr) || !std::isfinite(e.qcqc)) {
+        // NaN / overflowing parameters: lengths of +inf make every side plane fail the refusal test (zero normal, never culls)
+        e = EdgeBasis();
+        e.pp = e.qrqr = e.qcqc = std::numeric_limits<float>::infinity();
+    }
+    return e;
 }
 
 // log2 of the width of the squarest (on the view plane) rectangle of `pixels` pixels, clamped to [lo, hi]:

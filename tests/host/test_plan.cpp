@@ -651,8 +651,123 @@ static void test_direction_order()
     CHECK(order.empty() && pos_of.empty());
 }
 
+
+// EdgeBasis: the side planes of the culling pyramids from three per-frame vectors.  The device evaluates t P + Q in fp32
+// (-ffp-contract=off: a rounded product, a rounded sum); this test does the same in float and compares with the plane's normal
+// in double.  Beside it, the formula the kernels used before -- the fp32 cross product of the two corner directions -- on the
+// same edges: at 8K, for a tile at the frame's edge, it is off by more than the half pixel the pyramid is grown by.
+static void rotation(double pitch, double yaw, double roll, float m[16])
+{
+    const double cx = std::cos(pitch), sx = std::sin(pitch), cy = std::cos(yaw), sy = std::sin(yaw), cz = std::cos(roll), sz = std::sin(roll);
+    const double r[9] = {cy * cz + sy * sx * sz, -cy * sz + sy * sx * cz, sy * cx, cx * sz, cx * cz, -sx,
+                         -sy * cz + cy * sx * sz, sy * sz + cy * sx * cz, cy * cx};
+    for (int k = 0; k < 16; k++) m[k] = 0.0f;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) m[4 * i + j] = (float)r[3 * i + j];
+    }
+    m[15] = 1.0f;
+}
+
+static void test_edge_basis()
+{
+    std::mt19937 rng(99);
+    std::uniform_real_distribution<double> u(-1.0, 1.0);
+    double worst_new = 0.0, worst_old = 0.0, worst_contain = 0.0;
+    for (int it = 0; it < 400; it++) {
+        const uint64_t H = it % 3 == 0 ? 1080 : (it % 3 == 1 ? 2160 : 4320), W = H * 16 / 9;
+        const float e1 = 0.57735f * (float)H / 100.0f, e2 = 0.57735f;
+        float m[16];
+        rotation(0.4 * u(rng), 3.14159265 + 0.5 * u(rng), 0.4 * u(rng), m);
+        const EdgeBasis e = edge_basis(m, e1, e2);
+        auto dir = [&](double cx, double cy, double* w) {
+            for (int k = 0; k < 3; k++) w[k] = (double)m[4 * k] * (cx * e1) + (double)m[4 * k + 1] * (cy * e2) + (double)m[4 * k + 2];
+        };
+        auto dirf = [&](float cx, float cy, float* w) { // view_dir of the kernels, fp32
+            const float vx = cx * e1, vy = cy * e2;
+            for (int k = 0; k < 3; k++) w[k] = m[4 * k] * vx + m[4 * k + 1] * vy + m[4 * k + 2];
+        };
+        auto angle = [](const double* a, const double* b) { // between lines
+            const double c[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            return std::sqrt((c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) / ((a[0] * a[0] + a[1] * a[1] + a[2] * a[2]) * (b[0] * b[0] + b[1] * b[1] + b[2] * b[2])));
+        };
+        // a 16-column, 64-row tile at a random place, often at the frame's left or right edge
+        const uint64_t col0 = it % 2 ? (uint64_t)((W - 17) * (0.5 + 0.5 * u(rng))) : (it % 4 ? 0 : W - 16);
+        const uint64_t row0 = (uint64_t)((H - 65) * (0.5 + 0.5 * u(rng)));
+        const float fW = (float)W, fH = (float)H;
+        const float x0 = (2.0f * (float)col0 - 1.0f - fW) / fW, x1 = (2.0f * (float)(col0 + 16) - 1.0f - fW) / fW;
+        const float y0 = (fH - 2.0f * (float)row0 + 1.0f) / fH, y1 = (fH - 2.0f * (float)(row0 + 64) + 1.0f) / fH;
+        for (int k = 0; k < 4; k++) {
+            const bool row_edge = (k & 1) == 0;
+            const float t = row_edge ? (k == 0 ? y0 : y1) : (k == 1 ? -x1 : -x0);
+            const float* q = row_edge ? e.qr : e.qc;
+            float nf[3];
+            for (int i = 0; i < 3; i++) {
+                volatile float prod = t * e.p[i]; // (volatile: no contraction into an FMA, as on the device)
+                nf[i] = prod + q[i];
+            }
+            const double hyp2 = (double)t * t * e.pp + (row_edge ? e.qrqr : e.qcqc);
+            CHECK((double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2] >= 0.25 * hyp2); // a camera matrix never cancels
+            // the exact plane: through the two corner directions, in double
+            const double xa = (k == 1 || k == 2) ? x1 : x0, ya = k >= 2 ? y1 : y0, xb = ((k + 1) % 4 == 1 || (k + 1) % 4 == 2) ? x1 : x0, yb = (k + 1) % 4 >= 2 ? y1 : y0;
+            double wa[3], wb[3];
+            dir(xa, ya, wa);
+            dir(xb, yb, wb);
+            const double nt[3] = {wa[1] * wb[2] - wa[2] * wb[1], wa[2] * wb[0] - wa[0] * wb[2], wa[0] * wb[1] - wa[1] * wb[0]};
+            const double nd[3] = {nf[0], nf[1], nf[2]};
+            worst_new = std::max(worst_new, angle(nd, nt));
+            // every pixel direction along the edge lies in the plane
+            for (int sidx = 0; sidx <= 4; sidx++) {
+                double wm[3];
+                dir(xa + (xb - xa) * sidx / 4.0, ya + (yb - ya) * sidx / 4.0, wm);
+                const double dn = (nd[0] * wm[0] + nd[1] * wm[1] + nd[2] * wm[2]) /
+                                  std::sqrt((nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]) * (wm[0] * wm[0] + wm[1] * wm[1] + wm[2] * wm[2]));
+                worst_contain = std::max(worst_contain, std::fabs(dn));
+            }
+            // the former formula: cross product of the fp32 corner directions, in fp32
+            float fa[3], fb[3];
+            dirf((float)xa, (float)ya, fa);
+            dirf((float)xb, (float)yb, fb);
+            volatile float p0 = fa[1] * fb[2], p1 = fa[2] * fb[1], p2 = fa[2] * fb[0], p3 = fa[0] * fb[2], p4 = fa[0] * fb[1], p5 = fa[1] * fb[0];
+            const double no[3] = {(double)(float)(p0 - p1), (double)(float)(p2 - p3), (double)(float)(p4 - p5)};
+            worst_old = std::max(worst_old, angle(no, nt));
+        }
+    }
+    std::printf("edge planes: worst direction error %.2e rad (t P + Q), %.2e rad (fp32 cross product of corner directions); worst |n . w| %.2e\n",
+                worst_new, worst_old, worst_contain);
+    CHECK(worst_new < 6.0e-7);      // the kernel's comment says 4e-7 from the roundings, and the edge coordinates here are the same floats
+    CHECK(worst_contain < 6.0e-7);
+    CHECK(worst_old > 2.0e-5);      // why the formula changed (half a pixel at the 8K frame's edge is 5e-6 rad)
+    // degenerate parameters: never a plane that culls
+    float z[16] = {0};
+    EdgeBasis d = edge_basis(z, 1.0f, 1.0f);
+    CHECK(d.pp == 0.0f && d.qrqr == 0.0f && d.p[0] == 0.0f);          // zero normal -> the kernel's length test refuses it
+    z[0] = std::nanf("");
+    d = edge_basis(z, 1.0f, 1.0f);
+    CHECK(std::isinf(d.pp) && std::isinf(d.qrqr) && std::isinf(d.qcqc) && d.p[0] == 0.0f); // refusal test fails for every t
+    float big[16];
+    rotation(0.1, 0.2, 0.3, big);
+    d = edge_basis(big, 3.0e38f, 3.0e38f);
+    CHECK(std::isinf(d.pp) && d.qr[0] == 0.0f);
+    // a sheared matrix (column 1 nearly parallel to column 2): row edges near cy = -1/e2 cancel and are refused by the test the
+    // device applies, others are kept
+    float sh[16];
+    rotation(0.0, 0.0, 0.0, sh);
+    sh[1] = sh[2];
+    sh[5] = sh[6] + 1.0e-3f;
+    sh[9] = sh[10];
+    d = edge_basis(sh, 1.0f, 1.0f);
+    {
+        const float t = -1.0f;
+        float nf[3];
+        for (int i = 0; i < 3; i++) nf[i] = t * d.p[i] + d.qr[i];
+        const double len2 = (double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2];
+        CHECK(!(len2 >= 0.25 * ((double)t * t * d.pp + d.qrqr)));
+    }
+}
+
 int main()
 {
+    test_edge_basis();
     test_direction_order();
     test_view_density();
     test_tile_shapes();

@@ -853,3 +853,48 @@ def test_scenes_at_extreme_scales(R, ctx, scale):
         got = ctx.render_to_host(p, R.RGB_ASCII)
         assert_same(got, want, O.RGB_ASCII, w, "scale %g %s two-level %d" % (scale, kernel, two))
     set_kernel(R, ctx, "auto")
+
+
+@pytest.mark.parametrize("W,H,n", [(7680, 4320, 1024), (7680, 4320, 16384), (3840, 2160, 4096)])
+def test_thin_tiles_at_the_edge_of_a_wide_frame_with_a_turned_camera(R, W, H, n):
+    """The reference's horizontal tangent extent grows with the frame (element1 = 0.577 H / 100, Camera3D.cpp via SURVEY 8(d):
+    25 at 8K), so a 16-column tile at the left or right edge of an 8K frame spans 1.7e-4 rad.  The pyramids' side planes used
+    to be fp32 cross products of two corner directions -- nearly parallel there, and long -- and lost the plane by up to 7e-4
+    rad for a general camera matrix: culling kernels dropped pixels against the brute kernel (329 .. 12 841 per frame in 4 of
+    24 frames of tools/wide_view_cull_gpu.py).  Now y P + Qr / -x P + Qc (rtx_plan.hpp, EdgeBasis).  Every plan -- default,
+    one level, two levels, refined -- against the brute kernel (every pixel tests every object, RayTracing.cu:100-136)."""
+    import torch
+    rng = np.random.default_rng(7 + n)
+    p0 = R.camera_params(W, H)
+    sph, pl = R.synth_scene(100 + n, n, 1, p0.element1, p0.element2)
+    a, b = R.Context(W, H), R.Context(W, H)
+    try:
+        for c in (a, b):
+            c.set_scene(sph, pl)
+        b.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        for view in range(5):
+            rot = (float(rng.uniform(-0.3, 0.3)), float(np.pi + rng.uniform(-0.4, 0.4)), float(rng.uniform(-0.3, 0.3)))
+            pos = tuple(float(v) for v in rng.uniform(-2, 2, 3))
+            p = R.camera_params(W, H, pos, rot)
+            b.render_rows(p, R.RGB_ASCII, 0, H, d_out=want.data_ptr(), out_row_base=0)
+            b.synchronize()
+            for name, opts in (("auto", {}), ("one level", {R.OPT_TWO_LEVEL: 0}), ("two levels", {R.OPT_TWO_LEVEL: 1}),
+                               ("two levels, refined", {R.OPT_TWO_LEVEL: 1, R.OPT_REFINE: 1, R.OPT_SUBTILES: 2})):
+                a.set_option(R.OPT_TWO_LEVEL, -1)
+                a.set_option(R.OPT_REFINE, -1)
+                a.set_option(R.OPT_SUBTILES, 0)
+                for k, v in opts.items():
+                    a.set_option(k, v)
+                got.fill_(0xEE)
+                a.render_rows(p, R.RGB_ASCII, 0, H, d_out=got.data_ptr(), out_row_base=0)
+                a.synchronize()
+                if not torch.equal(got, want):
+                    diff = (got.view(H, W, 20) != want.view(H, W, 20)).any(dim=2)
+                    ys, xs = torch.nonzero(diff, as_tuple=True)
+                    raise AssertionError("%dx%d, %d spheres, view %d rot %r, %s (%s): %d pixels differ from the brute kernel's, columns %d..%d rows %d..%d"
+                                         % (W, H, n, view, rot, name, a.last_kernel, int(diff.sum()), int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max())))
+    finally:
+        a.close()
+        b.close()

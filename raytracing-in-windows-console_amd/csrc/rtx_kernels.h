@@ -21,10 +21,6 @@ struct KArgs {
     float ox, oy, oz;     // camPos
     float e1, e2, far;    // element1, element2, camFarDist
     float fW, fH;         // (float)W, (float)H
-    // the culling pyramids' side planes (rtx_plan.hpp, EdgeBasis): n_row(cy) = cy P + Qr, n_col(cx) = -cx P + Qc, and the
-    // squared lengths |P|^2, |Qr|^2, |Qc|^2 of the refusal test
-    float edge_p[3], edge_qr[3], edge_qc[3];
-    float edge_pp, edge_qrqr, edge_qcqc;
     uint32_t W, H;
     uint32_t row0, row_end;   // rows traced by this launch (global row indices)
     uint32_t out_row_base;    // the row stored at out[0]
@@ -85,6 +81,10 @@ struct KArgs {
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;
                               // 2 = RTX_RENDER_VALUES: out holds 8 floats per pixel (distance, shadingValue, normal, colour)
     // (experiment build only: its extra arguments; nothing in the product build)
+    // the culling pyramids' side planes (rtx_plan.hpp, EdgeBasis): n_row(cy) = cy P + Qr, n_col(cx) = -cx P + Qc, and the
+    // squared lengths |P|^2, |Qr|^2, |Qc|^2 of the refusal test
+    float edge_p[3], edge_qr[3], edge_qc[3];
+    float edge_pp, edge_qrqr, edge_qcqc;
 #define RTX_X_SECTION_KARGS
 #include "rtx_experiment.inc"
 #undef RTX_X_SECTION_KARGS

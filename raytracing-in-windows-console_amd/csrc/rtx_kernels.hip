@@ -127,7 +127,9 @@ __device__ __forceinline__ bool tile_culls_moving(const TileFrustum& f, float ox
 // pixel ray of the rectangle lies in the convex cone of the four corner directions, and the plane through the apex and an
 // edge cy = y (cx = x) has the normal y P + Qr (-x P + Qc) with three per-frame vectors (rtx_plan.hpp, EdgeBasis: computed
 // on the host in double).  NOT the cross product of the two corner directions: for a thin tile far off the view axis those
-// are nearly parallel and long, and the fp32 product loses the plane (8K, turned camera: up to 7e-4 rad, pixels lost).
+// are nearly parallel and long, and the fp32 product loses the plane (8K, first 16 columns: 4e-6 rad with the reference's own
+// camera matrices -- most of the half pixel, 5.3e-6 rad there -- and up to 8e-5 rad with a rolled camera, where a culling
+// kernel then drops rows of a large far sphere's cap: tools/wide_view_directed_gpu.py).
 // A normal that cannot be oriented or is ill-conditioned (degenerate or sheared matrix, NaN) becomes the zero vector,
 // which never culls.  This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the
 // slack in tile_culls covers their error and the normal's (4e-7 from the two roundings per component and the rounded

@@ -82,12 +82,13 @@ inline bool pixel_steps(const float inv_v[16], float e1, float e2, uint64_t W, u
 //   n_row(y) = y P + Qr,   n_col(x) = -x P + Qc,   P = A x B,  Qr = A x C,  Qc = B x C
 // (orientation is the caller's business).  The kernels used to take the cross product of the two corner DIRECTIONS in fp32;
 // at 8K the reference's horizontal tangent extent is 25 (element1 = 0.577 H / 100), a 16-column tile at the frame's edge
-// spans 1.7e-4 rad, and that cross product of two nearly parallel vectors of length 25 carries a direction error of up to
-// 7e-4 rad -- a hundred times the half pixel the pyramid is grown by: culling kernels lost pixels against the brute kernel
-// for turned cameras at 7680 x 4320 (tools/wide_view_cull_gpu.py).  P, Qr, Qc are cross products of (for a camera matrix)
-// perpendicular vectors, computed here in double from the fp32 parameters and rounded once; on the device one multiply-add per
-// component gives the normal to ~4e-7 whatever the tile's size.  pp, qrqr, qcqc are the squared lengths the device uses to
-// refuse an ill-conditioned sum (a sheared matrix: |y P + Qr|^2 < (y^2 |P|^2 + |Qr|^2) / 4 -> the plane never culls).
+// spans 1.7e-4 rad, and that cross product of two nearly parallel vectors of length 25 loses the plane: by 4e-6 rad with the
+// reference's own camera matrices (most of the half pixel the pyramid is grown by, 5.3e-6 rad there), by up to 8e-5 rad with a
+// rolled camera -- then a culling kernel drops rows of a large, far sphere's cap (tools/wide_view_directed_gpu.py).
+// P, Qr, Qc are cross products of (for a camera matrix) perpendicular vectors, computed here in double from the fp32
+// parameters and rounded once; on the device one multiply-add per component gives the normal to ~4e-7 whatever the tile's
+// size.  pp, qrqr, qcqc are the squared lengths the device uses to refuse an ill-conditioned sum (a sheared matrix:
+// |y P + Qr|^2 < (y^2 |P|^2 + |Qr|^2) / 4 -> the plane never culls).
 struct EdgeBasis {
     float p[3] = {0, 0, 0}, qr[3] = {0, 0, 0}, qc[3] = {0, 0, 0};
     float pp = 0, qrqr = 0, qcqc = 0;

@@ -856,13 +856,12 @@ def test_scenes_at_extreme_scales(R, ctx, scale):
 
 
 @pytest.mark.parametrize("W,H,n", [(7680, 4320, 1024), (7680, 4320, 16384), (3840, 2160, 4096)])
-def test_thin_tiles_at_the_edge_of_a_wide_frame_with_a_turned_camera(R, W, H, n):
-    """The reference's horizontal tangent extent grows with the frame (element1 = 0.577 H / 100, Camera3D.cpp via SURVEY 8(d):
-    25 at 8K), so a 16-column tile at the left or right edge of an 8K frame spans 1.7e-4 rad.  The pyramids' side planes used
-    to be fp32 cross products of two corner directions -- nearly parallel there, and long -- and lost the plane by up to 7e-4
-    rad for a general camera matrix: culling kernels dropped pixels against the brute kernel (329 .. 12 841 per frame in 4 of
-    24 frames of tools/wide_view_cull_gpu.py).  Now y P + Qr / -x P + Qc (rtx_plan.hpp, EdgeBasis).  Every plan -- default,
-    one level, two levels, refined -- against the brute kernel (every pixel tests every object, RayTracing.cu:100-136)."""
+def test_wide_frames_with_turned_cameras_culling_equals_brute(R, W, H, n):
+    """4K and 8K frames seen by turned cameras: every plan -- default, one level, two levels, refined -- against the brute kernel
+    (every pixel tests every object, RayTracing.cu:100-136).  The reference's horizontal tangent extent grows with the frame
+    (element1 = 0.577 H / 100: 25 at 8K), so tiles at the left and right edge are angularly thin (a 16-column tile at 8K: 1.7e-4
+    rad); App. D scenes shrink their spheres towards the edge, which is why this test never caught the plane error that the
+    directed test below constructs."""
     import torch
     rng = np.random.default_rng(7 + n)
     p0 = R.camera_params(W, H)
@@ -888,6 +887,7 @@ def test_thin_tiles_at_the_edge_of_a_wide_frame_with_a_turned_camera(R, W, H, n)
                 for k, v in opts.items():
                     a.set_option(k, v)
                 got.fill_(0xEE)
+                torch.cuda.synchronize()   # (the fill runs on torch's stream, the launch on the context's: order them)
                 a.render_rows(p, R.RGB_ASCII, 0, H, d_out=got.data_ptr(), out_row_base=0)
                 a.synchronize()
                 if not torch.equal(got, want):
@@ -898,3 +898,51 @@ def test_thin_tiles_at_the_edge_of_a_wide_frame_with_a_turned_camera(R, W, H, n)
     finally:
         a.close()
         b.close()
+
+
+def test_side_planes_of_thin_tiles_with_a_rolled_camera_at_8k(R):
+    """A directed scene for the culling pyramids' side planes (tools/wide_view_directed_gpu.py builds it): a camera matrix with roll
+    (any matrix is legal through rtx_params::inv_v; the reference's own Camera3D never rolls), 7680 x 4320, 16 x 16 tiles; for the
+    tiles of the first 16 columns the host emulates the fp32 cross product of corner directions that rounds 1-2 took as a side
+    plane's normal, picks the tiles whose own boundary-row pixel rays it leaves furthest outside (5e-5 .. 7e-5 rad; half a pixel
+    is 5.3e-6 there), and puts one sphere (r = 20, 200 away) per frame so that its extreme point pokes 2.5 rows into such a tile.
+    On the build before rtxplan::edge_basis the culling kernel dropped those rows in 5 of 6 frames (14 .. 46 pixels each, whole
+    tile widths); with y P + Qr / -x P + Qc every frame equals the brute kernel's."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from wide_view_directed_gpu import directed_scene
+    W, H = 7680, 4320
+    p, sph, report = directed_scene(R, W, H, (0.1, 2.8, 0.3), (1.0, 2.0, -1.0))
+    assert len(sph) >= 6, report
+    pl = np.zeros((0, 11), dtype=np.float32)
+    got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+    want = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+    for i in range(6):
+        a, b = R.Context(W, H), R.Context(W, H)
+        try:
+            for c in (a, b):
+                c.set_scene(sph[i:i + 1], pl)
+            b.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+            a.set_option(R.OPT_KERNEL, R.KERNEL_BINNED)
+            a.set_option(R.OPT_TWO_LEVEL, 0)
+            a.set_option(R.OPT_TILE_LOG2_W, 4)
+            a.set_option(R.OPT_SUBTILES, 1)
+            got.fill_(0xEE)
+            torch.cuda.synchronize()
+            b.render_rows(p, R.RGB_ASCII, 0, H, d_out=want.data_ptr(), out_row_base=0)
+            a.render_rows(p, R.RGB_ASCII, 0, H, d_out=got.data_ptr(), out_row_base=0)
+            a.synchronize()
+            b.synchronize()
+            assert a.last_kernel == "rtx_trace<RTX_K_RGB_ASCII,true>"
+            shaded = int((want.view(H, W, 20)[:, :16, 2] == ord('3')).sum().item())
+            assert shaded > 1000, "the directed sphere is not where it was put"
+            if not torch.equal(got, want):
+                diff = (got.view(H, W, 20) != want.view(H, W, 20)).any(dim=2)
+                ys, xs = torch.nonzero(diff, as_tuple=True)
+                raise AssertionError("directed sphere %d (%s): %d pixels differ from the brute kernel's, rows %d..%d columns %d..%d"
+                                     % (i, report[i], int(diff.sum()), int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max())))
+        finally:
+            a.close()
+            b.close()

@@ -81,10 +81,12 @@ struct KArgs {
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;
                               // 2 = RTX_RENDER_VALUES: out holds 8 floats per pixel (distance, shadingValue, normal, colour)
     // (experiment build only: its extra arguments; nothing in the product build)
-    // the culling pyramids' side planes (rtx_plan.hpp, EdgeBasis): n_row(cy) = cy P + Qr, n_col(cx) = -cx P + Qc, and the
-    // squared lengths |P|^2, |Qr|^2, |Qc|^2 of the refusal test
-    float edge_p[3], edge_qr[3], edge_qc[3];
+    // the culling pyramids' planes (rtx_plan.hpp, EdgeBasis): n_up(cy) = cy up_p + up_q and n_right(cx) = cx right_p + right_q,
+    // the normals of a row / column edge that point up / right in the frame; the squared lengths |P|^2, |Qr|^2, |Qc|^2 of the
+    // refusal test; the camera plane's unit normal (zero: none)
+    float edge_up_p[3], edge_up_q[3], edge_right_p[3], edge_right_q[3];
     float edge_pp, edge_qrqr, edge_qcqc;
+    float edge_fwd[3];
 #define RTX_X_SECTION_KARGS
 #include "rtx_experiment.inc"
 #undef RTX_X_SECTION_KARGS

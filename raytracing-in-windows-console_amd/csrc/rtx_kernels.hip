@@ -121,59 +121,42 @@ __device__ __forceinline__ bool tile_culls_moving(const TileFrustum& f, float ox
 }
 
 // One plane of the pyramid spanned by the pixel centres of columns [col0, col0+w) and rows [row0, row0+h), grown by
-// half a pixel on every side, selected by k: 0..3 the side through corners k and k+1 (corner order (x0,y0) (x1,y0)
-// (x1,y1) (x0,y1): k = 0 the row edge y0, 1 the column edge x1, 2 the row edge y1, 3 the column edge x0), 4 the axis plane --
-// arranged so that five lanes compute the five planes side by side.  Pixel directions are linear in (cx, cy), so every
-// pixel ray of the rectangle lies in the convex cone of the four corner directions, and the plane through the apex and an
-// edge cy = y (cx = x) has the normal y P + Qr (-x P + Qc) with three per-frame vectors (rtx_plan.hpp, EdgeBasis: computed
-// on the host in double).  NOT the cross product of the two corner directions: for a thin tile far off the view axis those
-// are nearly parallel and long, and the fp32 product loses the plane (8K, first 16 columns: 4e-6 rad with the reference's own
+// half a pixel on every side, selected by k: 0 the top edge (row0), 1 the right edge (col0 + w), 2 the bottom edge
+// (row0 + h), 3 the left edge (col0), 4 the camera plane -- arranged so that five lanes compute the five planes side by
+// side.  Pixel directions are linear in (cx, cy), so every pixel ray of the rectangle lies in the convex cone of the four
+// corner directions, and the plane through the apex and an edge cy = y (cx = x) has the normal y up_p + up_q (x right_p +
+// right_q), oriented up (right) in the frame, from per-frame vectors (rtx_plan.hpp, EdgeBasis: computed on the host in
+// double).  NOT the cross product of the two corner directions: for a thin tile far off the view axis those are nearly
+// parallel and long, and the fp32 product loses the plane (8K, first 16 columns: 4e-6 rad with the reference's own
 // camera matrices -- most of the half pixel, 5.3e-6 rad there -- and up to 8e-5 rad with a rolled camera, where a culling
 // kernel then drops rows of a large far sphere's cap: tools/wide_view_directed_gpu.py).
-// A normal that cannot be oriented or is ill-conditioned (degenerate or sheared matrix, NaN) becomes the zero vector,
-// which never culls.  This is culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the
-// slack in tile_culls covers their error and the normal's (4e-7 from the two roundings per component and the rounded
-// P, Q; 4e-7 from the edge coordinate's own rounding).
+// The fifth plane is the same for every rectangle of the frame: the camera plane (it culls what lies behind the apex; all
+// pixel rays of the frame point into its front half-space, which the host has checked).
+// An ill-conditioned normal (degenerate or sheared matrix, NaN) becomes the zero vector, which never culls.  This is
+// culling geometry, not reference arithmetic: hardware rcp/rsq (1 ulp) are used, and the slack in tile_culls covers their
+// error and the normal's (4e-7 from the two roundings per component and the rounded basis; 4e-7 from the edge
+// coordinate's own rounding).
 __device__ __forceinline__ V3 tile_plane(const KArgs& a, const Camera& c, uint32_t col0, uint32_t row0, uint32_t w, uint32_t h, uint32_t k)
 {
-    const float rW = __builtin_amdgcn_rcpf(c.fW), rH = __builtin_amdgcn_rcpf(c.fH);
-    const float x0 = (2.0f * (float)col0 - 1.0f - c.fW) * rW;
-    const float x1 = (2.0f * (float)(col0 + w) - 1.0f - c.fW) * rW;
-    const float y0 = (c.fH - 2.0f * (float)row0 + 1.0f) * rH;
-    const float y1 = (c.fH - 2.0f * (float)(row0 + h) + 1.0f) * rH;
-    const V3 axis = view_dir(c, 0.5f * (x0 + x1), 0.5f * (y0 + y1));
-    V3 n = axis;
     if (k == 4u) {
-        // The axis plane (it culls what lies behind the apex) is only a bound while every ray of the pyramid points
-        // into its front half-space, i.e. while all four corner directions do: a wide rectangle that straddles the
-        // view axis off-centre (a block of cells hanging over the frame's edge, a tile of a 5-pixel-wide frame) has
-        // corner rays more than 90 degrees from its own axis.  Then the plane is dropped (zero normal: never culls).
-        const V3 va = view_dir(c, x0, y0), vb = view_dir(c, x1, y0), vc = view_dir(c, x1, y1), vd = view_dir(c, x0, y1);
-        const float lo = fminf(fminf(dot(va, axis), dot(vb, axis)), fminf(dot(vc, axis), dot(vd, axis)));
-        if (!(lo > 0.0f)) {
-            return v3(0.0f, 0.0f, 0.0f);
-        }
-    } else {
-        const bool row_edge = (k & 1u) == 0u;
-        const float t = row_edge ? (k == 0u ? y0 : y1) : (k == 1u ? -x1 : -x0);
-        const V3 q = row_edge ? v3(a.edge_qr[0], a.edge_qr[1], a.edge_qr[2]) : v3(a.edge_qc[0], a.edge_qc[1], a.edge_qc[2]);
-        n = v3(t * a.edge_p[0] + q.x, t * a.edge_p[1] + q.y, t * a.edge_p[2] + q.z);
-        // refuse a sum that cancelled (the two terms are perpendicular for a camera matrix: no cancellation at all)
-        const float hyp2 = (t * t) * a.edge_pp + (row_edge ? a.edge_qrqr : a.edge_qcqc);
-        if (!(dot(n, n) >= 0.25f * hyp2)) {
-            return v3(0.0f, 0.0f, 0.0f);
-        }
+        return v3(a.edge_fwd[0], a.edge_fwd[1], a.edge_fwd[2]);
     }
-    float side = dot(n, axis);
-    if (!(side > 0.0f)) {
-        n = mulf(n, -1.0f);
-        side = -side;
-    }
+    const bool row_edge = (k & 1u) == 0u;
+    // the edge's coordinate: cy of row boundary e (half a pixel above row e), cx of column boundary e
+    const uint32_t e = row_edge ? row0 + (k == 2u ? h : 0u) : col0 + (k == 1u ? w : 0u);
+    const float t = row_edge ? (c.fH - 2.0f * (float)e + 1.0f) * __builtin_amdgcn_rcpf(c.fH) : (2.0f * (float)e - 1.0f - c.fW) * __builtin_amdgcn_rcpf(c.fW);
+    const V3 p = row_edge ? v3(a.edge_up_p[0], a.edge_up_p[1], a.edge_up_p[2]) : v3(a.edge_right_p[0], a.edge_right_p[1], a.edge_right_p[2]);
+    const V3 q = row_edge ? v3(a.edge_up_q[0], a.edge_up_q[1], a.edge_up_q[2]) : v3(a.edge_right_q[0], a.edge_right_q[1], a.edge_right_q[2]);
+    V3 n = v3(t * p.x + q.x, t * p.y + q.y, t * p.z + q.z);
+    // refuse a sum that cancelled (the two terms are perpendicular for a camera matrix: no cancellation at all)
+    const float hyp2 = (t * t) * a.edge_pp + (row_edge ? a.edge_qrqr : a.edge_qcqc);
     const float len2 = dot(n, n);
-    if (side > 0.0f && len2 > 1.0e-30f && len2 < 1.0e30f) {
-        return mulf(n, __builtin_amdgcn_rsqf(len2));
+    if (!(len2 >= 0.25f * hyp2) || !(len2 > 1.0e-30f && len2 < 1.0e30f)) {
+        return v3(0.0f, 0.0f, 0.0f);
     }
-    return v3(0.0f, 0.0f, 0.0f);
+    // inward: down from the top edge, left from the right edge, up from the bottom edge, right from the left edge
+    const float s = (k < 2u ? -1.0f : 1.0f) * __builtin_amdgcn_rsqf(len2);
+    return mulf(n, s);
 }
 
 // true when no pixel ray of the rectangle (columns [col0, col0+w), rows [row0, row0+h), half a pixel out, as for the
@@ -566,7 +549,7 @@ __device__ __forceinline__ float4 load_item(const Items& it, uint32_t i, uint32_
     return it.geom[k];
 }
 
-constexpr int kRefineSub = 4;      // REFINE: at most this many sub-tiles (lanes 5 .. 5 + 20 per sub-tile build the pyramids)
+constexpr int kRefineSub = 4;      // REFINE: at most this many sub-tiles (lanes 5 .. 5 + 16 per sub-tile build the pyramids)
 constexpr int kWaveListCap = 128;  // REFINE: candidates a wave keeps for its own 64 pixels; more -> it scans the whole list
 
 // REFINE (dense scenes, long candidate lists): before a wave scans the workgroup's list for its 64 pixels it
@@ -592,7 +575,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
     __shared__ float s_frustum[16];              // the macro tile's five plane normals
     __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
-    __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 5 : 1];               // REFINE: five plane normals per (sub-tile, wave)
+    __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 4 : 1];               // REFINE: four side-plane normals per (sub-tile, wave)
     __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
     __shared__ uint32_t s_cost[3];               // this tile's work estimate, summed over the waves; waves done; start time
     __shared__ uint32_t s_nplanes;               // planes of the LDS table this macro tile can see
@@ -696,15 +679,16 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // up from LDS into scalar registers.
     TileFrustum fr;
     if (CULL) {
-        const uint32_t plane_lanes = REFINE ? 5u + nsub * 20u : 5u;
+        const uint32_t plane_lanes = REFINE ? 5u + nsub * 16u : 5u;
         if (tid < ((plane_lanes + 63u) & ~63u)) { // wave 0, and wave 1 as well when REFINE needs more than 64 lanes
             // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along) ...
             uint32_t pc0 = mcol0, pr0 = mrow0, pw = mw, ph = mh, pk = tid;
             if (REFINE && tid >= 5u) {
-                // ... unless REFINE gives them the pyramids of the 64-pixel pieces: lane 5 + 5*region + k builds
-                // plane k of region = sub-tile * 4 + wave (a wave's pixels: all tw columns, 64/tw rows)
-                const uint32_t q = tid - 5u, region = q / 5u, sub = region >> 2, w = region & 3u;
-                pk = q - region * 5u;
+                // ... unless REFINE gives them the pyramids of the 64-pixel pieces: lane 5 + 4*region + k builds side
+                // plane k of region = sub-tile * 4 + wave (a wave's pixels: all tw columns, 64/tw rows; the camera plane
+                // is the macro tile's already)
+                const uint32_t q = tid - 5u, region = q >> 2, sub = region >> 2, w = region & 3u;
+                pk = q & 3u;
                 pc0 = mcol0 + (sub & (nx - 1u)) * tw;
                 pr0 = mrow0 + (sub >> lnx) * th + w * (64u >> lw);
                 pw = tw;
@@ -715,7 +699,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                 s_frustum[3 * tid + 0] = n.x;
                 s_frustum[3 * tid + 1] = n.y;
                 s_frustum[3 * tid + 2] = n.z;
-            } else if (REFINE && tid - 5u < nsub * 20u) {
+            } else if (REFINE && tid - 5u < nsub * 16u) {
                 s_wfr[tid - 5u] = make_float4(n.x, n.y, n.z, 0.0f);
             }
         }
@@ -808,10 +792,10 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             if (REFINE && total > 8u) {
                 // this wave's pyramid (uniform reads), then the list, one entry per lane
                 const uint32_t wave = tid >> 6, lane = tid & 63u;
-                V3 wn[5];
+                V3 wn[4];
 #pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const float4 pn = s_wfr[(j * 4u + wave) * 5u + (uint32_t)k];
+                for (int k = 0; k < 4; k++) {
+                    const float4 pn = s_wfr[(j * 4u + wave) * 4u + (uint32_t)k];
                     wn[k] = v3(pn.x, pn.y, pn.z);
                 }
                 uint32_t cnt = 0;
@@ -822,8 +806,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
                     const float mg = s_margin[ii];
                     bool out = false;
 #pragma unroll
-                    for (int k = 0; k < 5; k++) {
-                        out = out || (wn[k].x * sr.x + wn[k].y * sr.y + wn[k].z * sr.z > mg); // as tile_culls
+                    for (int k = 0; k < 4; k++) {
+                        out = out || (wn[k].x * sr.x + wn[k].y * sr.y + wn[k].z * sr.z > mg); // as tile_culls (every list entry has passed the camera plane)
                     }
                     const bool keepw = i < total && !out;
                     const unsigned long long m = __ballot(keepw);
@@ -1038,7 +1022,7 @@ __device__ __forceinline__ void bin_cells_of_block(const KArgs& a, const float4*
         const float4 r = s_rec[sv];
         bool out = false;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
+        for (int k = 0; k < 4; k++) { // (the four side planes: the block's survivors have passed the camera plane)
             const float4 nk = s_cellfr[c][k];
             out = out || (nk.x * r.x + nk.y * r.y + nk.z * r.z > r.w); // as tile_culls, margin in r.w (+inf: never)
         }

@@ -75,26 +75,38 @@ inline bool pixel_steps(const float inv_v[16], float e1, float e2, uint64_t W, u
     return true;
 }
 
-// The culling pyramids' side planes, well conditioned.  A pixel direction is linear in the view-plane point (cx, cy):
+// The culling pyramids' planes, well conditioned.  A pixel direction is linear in the view-plane point (cx, cy):
 //   w(cx, cy) = A cx + B cy + C,   A = e1 (m0, m4, m8),  B = e2 (m1, m5, m9),  C = (m2, m6, m10).
 // The plane through the apex and a ROW edge cy = y (all cx) has normal w(x0, y) x w(x1, y) = (x0 - x1) A x (B y + C), the plane
-// through a COLUMN edge cx = x has normal (y0 - y1) B x (A x + C):
-//   n_row(y) = y P + Qr,   n_col(x) = -x P + Qc,   P = A x B,  Qr = A x C,  Qc = B x C
-// (orientation is the caller's business).  The kernels used to take the cross product of the two corner DIRECTIONS in fp32;
-// at 8K the reference's horizontal tangent extent is 25 (element1 = 0.577 H / 100), a 16-column tile at the frame's edge
-// spans 1.7e-4 rad, and that cross product of two nearly parallel vectors of length 25 loses the plane: by 4e-6 rad with the
-// reference's own camera matrices (most of the half pixel the pyramid is grown by, 5.3e-6 rad there), by up to 8e-5 rad with a
-// rolled camera -- then a culling kernel drops rows of a large, far sphere's cap (tools/wide_view_directed_gpu.py).
-// P, Qr, Qc are cross products of (for a camera matrix) perpendicular vectors, computed here in double from the fp32
-// parameters and rounded once; on the device one multiply-add per component gives the normal to ~4e-7 whatever the tile's
-// size.  pp, qrqr, qcqc are the squared lengths the device uses to refuse an ill-conditioned sum (a sheared matrix:
-// |y P + Qr|^2 < (y^2 |P|^2 + |Qr|^2) / 4 -> the plane never culls).
+// through a COLUMN edge cx = x has normal (y0 - y1) B x (A x + C).  With P = A x B, Qr = A x C, Qc = B x C and the two signs
+// sr = sign(Qr . B), sc = sign(Qc . A) -- constants of the frame --
+//   n_up(y)    = sr ( y P + Qr)   is the normal of the row edge y that points towards larger cy (up the frame),
+//   n_right(x) = sc (-x P + Qc)   the normal of the column edge x that points towards larger cx,
+// so a rectangle's inward normals are -n_up(y_top), +n_up(y_bottom), +n_right(x_left), -n_right(x_right): no orientation test on
+// the device.  The kernels used to take the cross product of the two corner DIRECTIONS in fp32; at 8K the reference's
+// horizontal tangent extent is 25 (element1 = 0.577 H / 100), a 16-column tile at the frame's edge spans 1.7e-4 rad, and that
+// cross product of two nearly parallel vectors of length 25 loses the plane: by 4e-6 rad with the reference's own camera
+// matrices (most of the half pixel the pyramid is grown by, 5.3e-6 rad there), by up to 8e-5 rad with a rolled camera -- then a
+// culling kernel drops rows of a large, far sphere's cap (tools/wide_view_directed_gpu.py).  P, Qr, Qc are cross
+// products of (for a camera matrix) perpendicular vectors, computed here in double from the fp32 parameters and rounded once;
+// on the device one multiply-add per component gives the normal to ~4e-7 whatever the tile's size.  pp, qrqr, qcqc are the
+// squared lengths the device uses to refuse an ill-conditioned sum (a sheared matrix: |y P + Qr|^2 < (y^2 |P|^2 + |Qr|^2) / 4
+// -> the plane never culls).
+//
+// The fifth plane is ONE for the whole frame: fwd, the unit vector along C, when every pixel ray of the frame (half a pixel out,
+// like the pyramids) points into its front half-space by a margin -- true for every frame the reference can produce (tangent
+// extents are finite: less than 180 degrees).  It culls what lies behind the camera; the per-tile axis planes of rounds 1-2 did
+// the same job tile by tile (each needing its four corner directions checked against its own axis at the head of every
+// workgroup) and culled nothing more: what the four side planes of a tile let through behind the apex is a thin region along the
+// tile's backward axis, which lies behind the camera plane as well.  Zero when the frame is too wide or the matrix degenerate.
 struct EdgeBasis {
-    float p[3] = {0, 0, 0}, qr[3] = {0, 0, 0}, qc[3] = {0, 0, 0};
-    float pp = 0, qrqr = 0, qcqc = 0;
+    float up_p[3] = {0, 0, 0}, up_q[3] = {0, 0, 0};         // n_up(y) = y up_p + up_q
+    float right_p[3] = {0, 0, 0}, right_q[3] = {0, 0, 0};   // n_right(x) = x right_p + right_q
+    float pp = 0, qrqr = 0, qcqc = 0;                        // |P|^2, |Qr|^2, |Qc|^2, rounded up
+    float fwd[3] = {0, 0, 0};                                // unit normal of the camera plane, or zero
 };
 
-inline EdgeBasis edge_basis(const float inv_v[16], float e1, float e2)
+inline EdgeBasis edge_basis(const float inv_v[16], float e1, float e2, uint64_t W, uint64_t H)
 {
     const float* m = inv_v;
     const double A[3] = {(double)e1 * m[0], (double)e1 * m[4], (double)e1 * m[8]};
@@ -105,26 +117,52 @@ inline EdgeBasis edge_basis(const float inv_v[16], float e1, float e2)
         o[1] = a[2] * b[0] - a[0] * b[2];
         o[2] = a[0] * b[1] - a[1] * b[0];
     };
+    auto dot = [](const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
     double P[3], Qr[3], Qc[3];
     cross(A, B, P);
     cross(A, C, Qr);
     cross(B, C, Qc);
     EdgeBasis e;
-    bool ok = true;
-    for (int k = 0; k < 3; k++) {
-        e.p[k] = (float)P[k];
-        e.qr[k] = (float)Qr[k];
-        e.qc[k] = (float)Qc[k];
-        ok = ok && std::isfinite(e.p[k]) && std::isfinite(e.qr[k]) && std::isfinite(e.qc[k]);
+    const double det_r = dot(Qr, B), det_c = dot(Qc, A); // -det[A B C] and +det[A B C]
+    const double scale = std::sqrt(dot(A, A) * dot(B, B) * dot(C, C));
+    bool ok = std::isfinite(scale) && std::isfinite(det_r) && std::isfinite(det_c) && std::fabs(det_r) > 1e-9 * scale && std::fabs(det_c) > 1e-9 * scale;
+    const double sr = det_r > 0.0 ? 1.0 : -1.0, sc = det_c > 0.0 ? 1.0 : -1.0;
+    for (int k = 0; k < 3 && ok; k++) {
+        e.up_p[k] = (float)(sr * P[k]);
+        e.up_q[k] = (float)(sr * Qr[k]);
+        e.right_p[k] = (float)(-sc * P[k]);
+        e.right_q[k] = (float)(sc * Qc[k]);
+        ok = ok && std::isfinite(e.up_p[k]) && std::isfinite(e.up_q[k]) && std::isfinite(e.right_q[k]);
     }
-    // squared lengths, rounded UP a little: they only feed the refusal test, which must not be passed by rounding
-    e.pp = (float)((P[0] * P[0] + P[1] * P[1] + P[2] * P[2]) * (1.0 + 1e-6));
-    e.qrqr = (float)((Qr[0] * Qr[0] + Qr[1] * Qr[1] + Qr[2] * Qr[2]) * (1.0 + 1e-6));
-    e.qcqc = (float)((Qc[0] * Qc[0] + Qc[1] * Qc[1] + Qc[2] * Qc[2]) * (1.0 + 1e-6));
-    if (!ok || !std::isfinite(e.pp) || !std::isfinite(e.qrqr) || !std::isfinite(e.qcqc)) {
-        // NaN / overflowing parameters: lengths of +inf make every side plane fail the refusal test (zero normal, never culls)
+    if (ok) {
+        // squared lengths, rounded UP a little: they only feed the refusal test, which must not be passed by rounding
+        e.pp = (float)(dot(P, P) * (1.0 + 1e-6));
+        e.qrqr = (float)(dot(Qr, Qr) * (1.0 + 1e-6));
+        e.qcqc = (float)(dot(Qc, Qc) * (1.0 + 1e-6));
+        ok = std::isfinite(e.pp) && std::isfinite(e.qrqr) && std::isfinite(e.qcqc);
+    }
+    if (!ok) {
+        // degenerate, NaN or overflowing parameters: zero normals, and lengths of +inf make every side plane fail the refusal
+        // test as well -- nothing is ever culled
         e = EdgeBasis();
         e.pp = e.qrqr = e.qcqc = std::numeric_limits<float>::infinity();
+        return e;
+    }
+    // the camera plane: along C, if the frame's four corner rays (half a pixel out) all make less than ~89.99 degrees with it
+    const double cl = std::sqrt(dot(C, C));
+    if (cl > 0.0 && W > 0 && H > 0) {
+        const double f[3] = {C[0] / cl, C[1] / cl, C[2] / cl};
+        const double xs = 1.0 + 1.0 / (double)W, ys = 1.0 + 1.0 / (double)H;
+        double lo = 1.0;
+        for (int i = 0; i < 4; i++) {
+            const double cx = (i & 1) ? xs : -xs, cy = (i & 2) ? ys : -ys;
+            const double w[3] = {A[0] * cx + B[0] * cy + C[0], A[1] * cx + B[1] * cy + C[1], A[2] * cx + B[2] * cy + C[2]};
+            const double wl = std::sqrt(dot(w, w));
+            lo = std::fmin(lo, wl > 0.0 ? dot(w, f) / wl : -1.0);
+        }
+        if (lo > 1.0e-4) {
+            for (int k = 0; k < 3; k++) e.fwd[k] = (float)f[k];
+        }
     }
     return e;
 }

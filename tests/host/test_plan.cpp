@@ -678,7 +678,7 @@ static void test_edge_basis()
         const float e1 = 0.57735f * (float)H / 100.0f, e2 = 0.57735f;
         float m[16];
         rotation(0.4 * u(rng), 3.14159265 + 0.5 * u(rng), 0.4 * u(rng), m);
-        const EdgeBasis e = edge_basis(m, e1, e2);
+        const EdgeBasis e = edge_basis(m, e1, e2, W, H);
         auto dir = [&](double cx, double cy, double* w) {
             for (int k = 0; k < 3; k++) w[k] = (double)m[4 * k] * (cx * e1) + (double)m[4 * k + 1] * (cy * e2) + (double)m[4 * k + 2];
         };
@@ -698,12 +698,19 @@ static void test_edge_basis()
         const float y0 = (fH - 2.0f * (float)row0 + 1.0f) / fH, y1 = (fH - 2.0f * (float)(row0 + 64) + 1.0f) / fH;
         for (int k = 0; k < 4; k++) {
             const bool row_edge = (k & 1) == 0;
-            const float t = row_edge ? (k == 0 ? y0 : y1) : (k == 1 ? -x1 : -x0);
-            const float* q = row_edge ? e.qr : e.qc;
+            const float t = row_edge ? (k == 0 ? y0 : y1) : (k == 1 ? x1 : x0);
+            const float* pb = row_edge ? e.up_p : e.right_p;
+            const float* q = row_edge ? e.up_q : e.right_q;
             float nf[3];
             for (int i = 0; i < 3; i++) {
-                volatile float prod = t * e.p[i]; // (volatile: no contraction into an FMA, as on the device)
-                nf[i] = prod + q[i];
+                volatile float prod = t * pb[i]; // (volatile: no contraction into an FMA, as on the device)
+                nf[i] = (k < 2 ? -1.0f : 1.0f) * (prod + q[i]); // inward: down from the top, left from the right, up from the bottom, right from the left
+            }
+            {
+                // ... and inward it is: positive on the rectangle's central direction
+                double wc[3];
+                dir(0.5 * ((double)x0 + x1), 0.5 * ((double)y0 + y1), wc);
+                CHECK((double)nf[0] * wc[0] + (double)nf[1] * wc[1] + (double)nf[2] * wc[2] > 0.0);
             }
             const double hyp2 = (double)t * t * e.pp + (row_edge ? e.qrqr : e.qcqc);
             CHECK((double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2] >= 0.25 * hyp2); // a camera matrix never cancels
@@ -737,17 +744,44 @@ static void test_edge_basis()
     CHECK(worst_new < 6.0e-7);      // the kernel's comment says 4e-7 from the roundings, and the edge coordinates here are the same floats
     CHECK(worst_contain < 6.0e-7);
     CHECK(worst_old > 2.0e-5);      // why the formula changed (half a pixel at the 8K frame's edge is 5e-6 rad)
+    // the camera plane: every pixel ray of the frame in front of it, for every frame size the reference's camera produces
+    for (uint64_t H : {180ull, 1080ull, 4320ull, 17280ull}) {
+        const uint64_t W = H * 16 / 9;
+        float m[16];
+        rotation(0.3, 2.0, -0.2, m);
+        const float e1 = 0.57735f * (float)H / 100.0f, e2 = 0.57735f;
+        const EdgeBasis e = edge_basis(m, e1, e2, W, H);
+        CHECK(std::fabs((double)e.fwd[0] * e.fwd[0] + (double)e.fwd[1] * e.fwd[1] + (double)e.fwd[2] * e.fwd[2] - 1.0) < 1e-6);
+        for (int i = 0; i < 4; i++) {
+            const double cx = (i & 1) ? 1.0 : -1.0, cy = (i & 2) ? 1.0 : -1.0;
+            double w[3];
+            for (int k = 0; k < 3; k++) w[k] = (double)m[4 * k] * (cx * e1) + (double)m[4 * k + 1] * (cy * e2) + (double)m[4 * k + 2];
+            CHECK(e.fwd[0] * w[0] + e.fwd[1] * w[1] + e.fwd[2] * w[2] > 0.0);
+        }
+    }
+    {
+        // a frame so wide that its corner rays are within 1e-4 of perpendicular to the axis: no camera plane
+        float m[16];
+        rotation(0.0, 0.0, 0.0, m);
+        const EdgeBasis e = edge_basis(m, 3.0e4f, 0.5f, 1920, 1080);
+        CHECK(e.fwd[0] == 0.0f && e.fwd[1] == 0.0f && e.fwd[2] == 0.0f && e.pp > 0.0f);
+    }
     // degenerate parameters: never a plane that culls
     float z[16] = {0};
-    EdgeBasis d = edge_basis(z, 1.0f, 1.0f);
-    CHECK(d.pp == 0.0f && d.qrqr == 0.0f && d.p[0] == 0.0f);          // zero normal -> the kernel's length test refuses it
+    EdgeBasis d = edge_basis(z, 1.0f, 1.0f, 640, 360);
+    CHECK(std::isinf(d.pp) && d.up_p[0] == 0.0f && d.up_q[0] == 0.0f && d.fwd[2] == 0.0f);
     z[0] = std::nanf("");
-    d = edge_basis(z, 1.0f, 1.0f);
-    CHECK(std::isinf(d.pp) && std::isinf(d.qrqr) && std::isinf(d.qcqc) && d.p[0] == 0.0f); // refusal test fails for every t
+    d = edge_basis(z, 1.0f, 1.0f, 640, 360);
+    CHECK(std::isinf(d.pp) && std::isinf(d.qrqr) && std::isinf(d.qcqc) && d.up_p[0] == 0.0f && d.fwd[0] == 0.0f); // refusal test fails for every t
     float big[16];
     rotation(0.1, 0.2, 0.3, big);
-    d = edge_basis(big, 3.0e38f, 3.0e38f);
-    CHECK(std::isinf(d.pp) && d.qr[0] == 0.0f);
+    d = edge_basis(big, 3.0e38f, 3.0e38f, 640, 360);
+    CHECK(std::isinf(d.pp) && d.up_q[0] == 0.0f);
+    float flat[16];
+    rotation(0.1, 0.2, 0.3, flat);
+    flat[2] = flat[6] = flat[10] = 0.0f; // no third column: every direction in one plane
+    d = edge_basis(flat, 1.0f, 1.0f, 640, 360);
+    CHECK(std::isinf(d.pp) && d.right_q[0] == 0.0f);
     // a sheared matrix (column 1 nearly parallel to column 2): row edges near cy = -1/e2 cancel and are refused by the test the
     // device applies, others are kept
     float sh[16];
@@ -755,11 +789,11 @@ static void test_edge_basis()
     sh[1] = sh[2];
     sh[5] = sh[6] + 1.0e-3f;
     sh[9] = sh[10];
-    d = edge_basis(sh, 1.0f, 1.0f);
+    d = edge_basis(sh, 1.0f, 1.0f, 640, 360);
     {
         const float t = -1.0f;
         float nf[3];
-        for (int i = 0; i < 3; i++) nf[i] = t * d.p[i] + d.qr[i];
+        for (int i = 0; i < 3; i++) nf[i] = t * d.up_p[i] + d.up_q[i];
         const double len2 = (double)nf[0] * nf[0] + (double)nf[1] * nf[1] + (double)nf[2] * nf[2];
         CHECK(!(len2 >= 0.25 * ((double)t * t * d.pp + d.qrqr)));
     }

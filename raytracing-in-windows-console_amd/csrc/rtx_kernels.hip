@@ -68,7 +68,7 @@ constexpr float kKappa = 2.0e-6f;
 constexpr float kDelta = 5.0e-6f;
 
 struct TileFrustum {
-    V3 n[5]; // inward unit normals of the four side planes, then the tile axis
+    V3 n[5]; // inward unit normals of the four side planes, then the frame's camera plane
 };
 
 __device__ __forceinline__ V3 cross(V3 a, V3 b)
@@ -636,19 +636,29 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
         // past the count), which takes one round trip to memory out of the chain.
         const uint32_t* lst = a.cell_list + (size_t)cell * a.cell_cap;
         const uint32_t cap1 = a.cell_cap - 1u;
-        const uint32_t e0 = lst[tid < cap1 ? tid : cap1], e1 = lst[(uint32_t)kThreads + tid < cap1 ? (uint32_t)kThreads + tid : cap1];
+        // The sparse plan's lists rarely reach 256 entries (config 2: 60 .. 250), so there only the first half of the step is
+        // requested ahead (slots past the end are cold lines every frame: 512 slots per workgroup cost config 2 2.1 MB of
+        // reads per frame against 0.8 MB for the whole scene); the dense plan's lists (config 5: ~250 on average) take both.
+        const uint32_t e0 = lst[tid < cap1 ? tid : cap1];
+        uint32_t e1 = 0u;
+        if (REFINE) e1 = lst[(uint32_t)kThreads + tid < cap1 ? (uint32_t)kThreads + tid : cap1];
         const uint32_t listed = a.cell_count[cell];
         // (their geometry too, unconditionally: behind a test of the count the compiler would sink the whole step behind the wait
         // for the count)
         const uint32_t last = a.ns - 1u;
         k0 = e0 < a.ns ? e0 : last;
-        k1 = e1 < a.ns ? e1 : last;
         g0 = items.geom[k0];
-        g1 = items.geom[k1];
+        if (REFINE) {
+            k1 = e1 < a.ns ? e1 : last;
+            g1 = items.geom[k1];
+        }
         if (listed <= a.cell_cap) { // else: the list did not fit; the whole scene is always a superset
             items.list = lst;
             items.count = listed;
             first_step_requested = listed != 0u && !ABL(1u);
+            if (!REFINE && first_step_requested) {
+                g1 = load_item(items, (uint32_t)kThreads + tid, k1); // (at most 256 entries: every lane reads the last one)
+            }
         }
     }
     if (ABL(1u)) items.count = 0u;
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     if (CULL) {
         const uint32_t plane_lanes = REFINE ? 5u + nsub * 16u : 5u;
         if (tid < ((plane_lanes + 63u) & ~63u)) { // wave 0, and wave 1 as well when REFINE needs more than 64 lanes
-            // lanes 0..3 each build one side plane, lane 4 the axis plane (the other lanes idle along) ...
+            // lanes 0..3 each build one side plane, lane 4 picks up the camera plane (the other lanes idle along) ...
             uint32_t pc0 = mcol0, pr0 = mrow0, pw = mw, ph = mh, pk = tid;
             if (REFINE && tid >= 5u) {
                 // ... unless REFINE gives them the pyramids of the 64-pixel pieces: lane 5 + 4*region + k builds side

@@ -656,8 +656,10 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
             items.list = lst;
             items.count = listed;
             first_step_requested = listed != 0u && !ABL(1u);
-            if (!REFINE && first_step_requested) {
-                g1 = load_item(items, (uint32_t)kThreads + tid, k1); // (at most 256 entries: every lane reads the last one)
+            if (!REFINE && first_step_requested && listed > (uint32_t)kThreads) {
+                // (rare in the sparse plan; the count has long arrived by now -- it was requested beside the first entries, one
+                // round trip against their two -- so the common case pays nothing for this test)
+                g1 = load_item(items, (uint32_t)kThreads + tid, k1);
             }
         }
     }

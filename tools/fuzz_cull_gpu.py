@@ -5,7 +5,7 @@ matrices (roll, slight non-orthonormality), fields of view from a fifth to twice
 that are large and far / tiny / around and behind the camera / containing it, up to 20 planes, every tile shape, lists that
 outlive the frame while the camera creeps.  Prints one line per differing frame with the seed that reproduces it.
 
-  python tools/fuzz_cull_gpu.py [seconds] [first_seed]
+  python tools/fuzz_cull_gpu.py [seconds] [first_seed] [--physics]
 """
 import importlib
 import os
@@ -21,6 +21,7 @@ import torch  # noqa: E402
 R = importlib.import_module("raytracing-in-windows-console_amd")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+PHYSICS = "--physics" in sys.argv
 SIZES = [(1920, 1080), (3840, 2160), (7680, 4320), (1280, 720), (640, 360), (333, 77), (2560, 300), (97, 1201)]
 
 
@@ -100,7 +101,20 @@ while time.time() < t_end:
             a.set_option(k, v)
         mode = int(g.choice([R.RGB_ASCII, R.RGB_ASCII, R.BIT_ASCII, R.RGB_NORMALS]))
         creep = g.random() < 0.5
-        for f in range(4 if creep else 1):
+        # physics: a third of the creeping runs also step their spheres between frames (Sphere::Update, Sphere.cu:15-23: y moves by
+        # speed * mover * dt and is clamped to +-10) on both contexts alike; the lists' position budget has to cover it
+        physics = creep and PHYSICS and g.random() < 0.6 and len(sph) <= 3000
+        if physics:
+            movers = g.choice([-1, 1], len(sph))
+            speeds = g.uniform(0.5, 4.0, len(sph))
+            for i in range(len(sph)):
+                for c in (a, b):
+                    c.set_sphere_motion(i, int(movers[i]), float(speeds[i]))
+        for f in range((8 if physics else 4) if creep else 1):
+            if physics:
+                dt = float(g.choice([0.004, 0.016, 0.033]))
+                for c in (a, b):
+                    c.update_objects(dt)
             if f:
                 # creep: a small turn about a random axis and a small step, so that lists built for an earlier frame are reused
                 w = g.normal(0, 1, 3) * 2e-4

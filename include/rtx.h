@@ -92,8 +92,11 @@ enum rtx_option {
                                * order.  -1 = auto (default): on for tile grids whose workgroups are all resident at once (5 or 6
                                * sub-tiles per workgroup are chosen to make that so, e.g. at 1080p); those are balanced by
                                * rtx_balance_tiles on a stream of the library's own, every 4th frame for the first 64 frames of a
-                               * grid, then every 64th (one 1080p launch alone: 29.3 -> 25.9 us).  Off for larger grids, where
-                               * ordering gains nothing and at 8K costs 10 % by separating tiles that share 128-byte lines.
+                               * grid, then every 64th (one 1080p launch alone: 29.3 -> 25.9 us).  Larger grids (several dispatch
+                               * rounds, up to six): heaviest first only while the caller renders on a single stream -- then nothing
+                               * overlaps the end of a launch, and the workgroups dispatched last should be the light ones (a dense
+                               * 1080p scene alone 44.6 -> 41.4 us); with frames in flight on several streams the order gains
+                               * nothing, costs 1-2 % and at 8K 10 % by separating tiles that share 128-byte lines: off.
                                * 0 = frame order; k > 0 = on for every grid, the order re-derived every k-th frame */
     RTX_OPT_CELL_REUSE = 8,   /* coarse-cell lists of that pre-pass outlive the frame: binned with every sphere's culling margin grown by a
                                * motion budget (about sixteen frames of the camera's and the spheres' current motion), the lists serve

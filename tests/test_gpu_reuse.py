@@ -459,3 +459,47 @@ def test_exact_ties_are_broken_by_creation_order_with_sorted_arrays(R):
             assert np.array_equal(got, want_bit), srt
     finally:
         c.close()
+
+
+def test_grids_of_several_rounds_go_heaviest_first_only_on_a_lone_stream(R):
+    """RTX_OPT_TILE_ORDER auto on a tile grid of several dispatch rounds (a dense 1080p scene: 4050 workgroups for 1792 slots):
+    while every launch comes on one stream the library derives heaviest-first orders (rtx_order_tiles, every 16th frame) --
+    nothing overlaps a launch's tail there -- and stops when frames arrive on several streams.  The frame is the brute kernel's
+    under every order."""
+    import torch
+    W, H, n = 1920, 1080, 16384
+    sph, pl = _dense_scene(R, W, H, n, 21)
+    a, b = _pair(R, W, H, sph, pl)
+    try:
+        p = R.camera_params(W, H)
+        got = torch.empty(20 * W * H, dtype=torch.uint8, device="cuda")
+        want = torch.empty_like(got)
+        _frame(b, p, O.RGB_ASCII, want)
+        b.synchronize()
+        passes0 = a.get_option(R.STAT_ORDER_PASSES)
+        for f in range(40):
+            _frame(a, p, O.RGB_ASCII, got)
+            a.synchronize()
+            if f in (0, 1, 2, 17, 39):
+                assert torch.equal(got, want), "frame %d on a lone stream" % f
+        assert a.last_kernel.endswith(",refine>")
+        lone = a.get_option(R.STAT_ORDER_PASSES) - passes0
+        assert lone >= 3, "no dispatch order derived on a lone stream: %d passes" % lone
+        # two streams, alternating: the order is no longer derived (the static XCD order serves)
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        for f in range(20):
+            st = (s1, s2)[f % 2]
+            _frame(a, p, O.RGB_ASCII, got, stream=st.cuda_stream)
+            st.synchronize()
+            if f in (0, 19):
+                assert torch.equal(got, want), "frame %d on two streams" % f
+        before = a.get_option(R.STAT_ORDER_PASSES)
+        for f in range(20):
+            st = (s1, s2)[f % 2]
+            _frame(a, p, O.RGB_ASCII, got, stream=st.cuda_stream)
+            st.synchronize()
+        assert torch.equal(got, want)
+        assert a.get_option(R.STAT_ORDER_PASSES) == before, "orders still derived with frames on two streams"
+    finally:
+        a.close()
+        b.close()

@@ -79,6 +79,7 @@ struct rtx_ctx {
         size_t cap = 0;              // tiles the buffers hold
         uint64_t last_use = 0;       // ctx->order_clock at the last launch (least recently used set is recycled)
         bool frozen = false;         // a recorded (HIP graph) launch reads the order in use: nothing is derived for this set any more
+        const uint32_t* base = nullptr; // the static XCD-aware order of the launch in hand, or nullptr (rtx_order_tiles sorts per XCD label within it)
         rtxplan::DispatchOrder plan;
     };
     std::vector<TileOrder> tile_orders;

@@ -121,5 +121,6 @@ int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 // order; may be tile_order itself).
 int rtx_k_launch_balance_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, const uint32_t* prev_order, float* factor,
                                int have_factor, int have_times, uint32_t* tile_order, void* stream);
-int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round, uint32_t* tile_order, void* stream);
+int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round, const uint32_t* base_order,
+                             uint32_t* tile_order, void* stream);
 }

@@ -1250,11 +1250,17 @@ __global__ __launch_bounds__(kThreads) void rtx_zero_fill(uint32_t* p, size_t n_
 // carries the same work, and the light remainder fills the slots as they free up.
 constexpr int kOrderThreads = 1024, kOrderBins = 1024;
 
+// With `base` (the static XCD-aware order of a two-level grid: position -> packed tile, blocks b, b + 8, ... share an XCD and are
+// handed whole cells, rtx_plan.hpp xcd_cell_order) the sort is PER LABEL: the tiles at the positions p = L mod 8 of `base` are
+// put back, heaviest first, at the same positions -- every XCD keeps its cells (and its L2 their lists and spheres: config 5's
+// trace kernel fetches 6 MB per launch this way and 19 MB under a plain heaviest-first order), within an XCD the heavy tiles
+// come first.  1024 classes = 8 labels x 128 cost classes; a tile's position is 8 x (its rank within the label) + label.
 __global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t* __restrict__ cost, uint32_t n, uint32_t gx, uint32_t n_cu,
-                                                                  uint32_t first_round, uint32_t* __restrict__ order)
+                                                                  uint32_t first_round, const uint32_t* __restrict__ base, uint32_t* __restrict__ order)
 {
     __shared__ uint32_t s_hist[kOrderBins];
     __shared__ uint32_t s_lo[kOrderThreads / 64], s_hi[kOrderThreads / 64];
+    __shared__ uint32_t s_start[8];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     uint32_t lo = 0xffffffffu, hi = 0u;
     for (uint32_t i = tid; i < n; i += kOrderThreads) {
@@ -1281,8 +1287,11 @@ __global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t*
     }
     const uint64_t range = (uint64_t)(hi - lo) + 1u;
     auto bin_of = [&](uint32_t c) { return (uint32_t)(((uint64_t)(hi - c) * (uint64_t)kOrderBins) / range); }; // 0 = heaviest
+    // per label: the class of the tile at position p of `base`
+    auto tile_at = [&](uint32_t p) { const uint32_t packed = base[p]; return (packed >> 16) * gx + (packed & 0xffffu); };
+    auto class_at = [&](uint32_t p) { return ((p & 7u) << 7) | (bin_of(cost[tile_at(p)]) >> 3); };
     for (uint32_t i = tid; i < n; i += kOrderThreads) {
-        atomicAdd(&s_hist[bin_of(cost[i])], 1u);
+        atomicAdd(&s_hist[base != nullptr ? class_at(i) : bin_of(cost[i])], 1u);
     }
     __syncthreads();
     // exclusive prefix sum over the classes (one per thread): wave scan, then the waves' totals
@@ -1302,7 +1311,16 @@ __global__ __launch_bounds__(kOrderThreads) void rtx_order_tiles(const uint32_t*
         before += (uint32_t)k < wave ? s_lo[k] : 0u;
     }
     s_hist[tid] = before + incl - mine; // now: next free rank of the class
+    if ((tid & 127u) == 0u) s_start[tid >> 7] = before + incl - mine; // (per label: where its ranks begin)
     __syncthreads();
+    if (base != nullptr) {
+        for (uint32_t p = tid; p < n; p += kOrderThreads) {
+            const uint32_t label = p & 7u;
+            const uint32_t rank = atomicAdd(&s_hist[class_at(p)], 1u) - s_start[label];
+            order[8u * rank + label] = base[p]; // (the label's set has exactly as many tiles as there are positions = label mod 8)
+        }
+        return;
+    }
     const uint32_t rounds = n_cu ? first_round / n_cu : 0u; // whole rounds dealt boustrophedon
     for (uint32_t i = tid; i < n; i += kOrderThreads) {
         const uint32_t rank = atomicAdd(&s_hist[bin_of(cost[i])], 1u);
@@ -1722,13 +1740,13 @@ extern "C" int rtx_k_launch_bin_cells(const KArgs* a, unsigned splits, void* str
 }
 
 extern "C" int rtx_k_launch_order_tiles(const uint32_t* tile_cost, uint32_t n_tiles, uint32_t gx, uint32_t n_cu, uint32_t first_round,
-                                        uint32_t* tile_order, void* stream_v)
+                                        const uint32_t* base_order, uint32_t* tile_order, void* stream_v)
 {
     if (n_tiles == 0 || gx == 0 || gx > 0xffffu || (n_tiles + gx - 1u) / gx > 0xffffu) {
         return (int)hipErrorInvalidValue;
     }
     if (first_round > n_tiles) first_round = n_tiles;
-    hipLaunchKernelGGL(rtx::rtx_order_tiles, dim3(1), dim3(rtx::kOrderThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, first_round, tile_order);
+    hipLaunchKernelGGL(rtx::rtx_order_tiles, dim3(1), dim3(rtx::kOrderThreads), 0, (hipStream_t)stream_v, tile_cost, n_tiles, gx, n_cu, first_round, base_order, tile_order);
     return (int)hipGetLastError();
 }
 

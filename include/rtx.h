@@ -130,7 +130,7 @@ enum rtx_stat {
     RTX_STAT_CELL_HITS = 103,       /* launches served by cached lists */
     RTX_STAT_CELL_PER_FRAME = 104,  /* launches that binned for themselves alone (reuse off, or a fast camera) */
     RTX_STAT_ORDER_PASSES = 105,    /* dispatch-order passes queued (rtx_balance_tiles / rtx_order_tiles) */
-    RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a recorded launch reads (kept as they are from then on) */
+    RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a live recorded graph reads (kept as they are until it is destroyed) */
     RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
     RTX_STAT_CELL_CAPACITY_FLOOR = 107 /* entries per cell list the current grid is planned with at least (0: the default capacity has
@@ -189,7 +189,9 @@ int rtx_scene_add_plane(rtx_ctx* ctx, const float pos[3], const float normal[3],
 /* Bulk append: n records of 7 floats (cx cy cz r R G B). */
 int rtx_scene_add_spheres(rtx_ctx* ctx, size_t n, const float* xyzr_rgb);
 unsigned rtx_scene_count(const rtx_ctx* ctx);
-/* Sphere::mover / Sphere::speed (Sphere.cu:9-12): the reference draws speed from rand(); here the caller sets it. */
+/* Sphere::mover / Sphere::speed (Sphere.cu:9-12): the reference draws speed from rand(); here the caller sets it.
+ * The reference only ever holds mover = -1 or +1 (Sphere.cu:9,21); any int is accepted, a step then moves the sphere by
+ * speed * mover * dt (Sphere.cu:17) and the library's motion bounds (cell-list reuse, dispatch orders) count |speed * mover|. */
 int rtx_scene_set_sphere_motion(rtx_ctx* ctx, unsigned index, int mover, float speed);
 /* Reads object `index` back from the device store: type (1 plane, 2 sphere, Object3D.h:14) and
  * 11 floats (sphere: cx cy cz r R G B mover speed 0 0; plane: px py pz nx ny nz R G B w h). */
@@ -247,7 +249,7 @@ int rtx_expand(rtx_ctx* ctx, int mode, const void* d_compact, void* d_out, const
  * edit"; rtx_update_objects moves spheres in place and is fine).  Recorded launches need caller buffers (not the
  * context's own frame, whose zero-fill depends on what earlier launches left in it).  Dispatch order: nothing is derived
  * while recording; a recorded launch runs under the order its tile grid has converged to on that stream, if any -- that
- * order is then frozen for good -- and in frame order otherwise.
+ * order is then frozen while a graph that reads it lives (rtx_graph_destroy of the last one releases it) -- and in frame order otherwise.
  * Not recordable, and reported as RTX_ERR_INVALID_ARGUMENT: a launch that needs a scene upload (render once before
  * capturing) or the two-level pre-pass (its lists change from launch to launch).
  * No reference counterpart (one launch per frame on the default stream, RayTracingManager.cu:127-134). */

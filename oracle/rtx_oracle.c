@@ -438,59 +438,77 @@ int orc_render_rows(const orc_params* p, const orc_object* const* objects, unsig
     return 0;
 }
 
-typedef struct mt_job {
+/* One row of the frame into a buffer of its own (x * S bytes, S = 12 or 20 by mode; zero-initialised by the caller):
+ * what a checker needs when the frame is 8K and only a few rows are to be compared. */
+int orc_render_row(const orc_params* p, const orc_object* const* objects, unsigned count, int mode,
+                   size_t row, int flags, char* row_out)
+{
+    const size_t S = (mode == ORC_BIT_ASCII || mode == ORC_BIT_PIXEL) ? 12u : 20u;
+    /* orc_render_rows addresses the record of (row, col) at result + row * x * S + col * S: hand it the address
+     * that puts this row's first record at row_out (integer arithmetic: no pointer outside an object is formed) */
+    char* base = (char*)((uintptr_t)row_out - (uintptr_t)(row * p->x * S));
+    return orc_render_rows(p, objects, count, mode, row, 1, flags, base, NULL);
+}
+
+typedef struct mt_shared {
     const orc_params* p;
     const orc_object* const* objects;
     unsigned count;
     int mode, flags;
-    size_t row0, rows;
+    size_t next_row; /* first row nobody has taken yet (atomic) */
     char* result;
-} mt_job;
+} mt_shared;
+
+/* rows a worker takes at a time: small enough that the last blocks end together whatever the scene's
+ * density per row, large enough that the shared counter is touched once per ~10^4 pixels */
+#define ORC_MT_BLOCK_ROWS 4
 
 static void* mt_worker(void* arg)
 {
-    mt_job* j = (mt_job*)arg;
-    orc_render_rows(j->p, j->objects, j->count, j->mode, j->row0, j->rows, j->flags, j->result, NULL);
+    mt_shared* j = (mt_shared*)arg;
+    const size_t H = j->p->y;
+    for (;;) {
+        const size_t row0 = __atomic_fetch_add(&j->next_row, (size_t)ORC_MT_BLOCK_ROWS, __ATOMIC_RELAXED);
+        if (row0 >= H) {
+            break;
+        }
+        orc_render_rows(j->p, j->objects, j->count, j->mode, row0, ORC_MT_BLOCK_ROWS, j->flags, j->result, NULL);
+    }
     return NULL;
 }
 
 int orc_render_mt(const orc_params* p, const orc_object* const* objects, unsigned count, int mode,
                   int flags, int nthreads, char* result)
 {
+    if (mode < ORC_BIT_ASCII || mode > ORC_SDL) {
+        return -1; /* RayTracing.cu:863-865 asserts */
+    }
     if (nthreads < 1) {
         nthreads = 1;
     }
-    if (nthreads > 256) {
-        nthreads = 256;
+    if (nthreads > 1024) {
+        nthreads = 1024;
     }
-    /* Interleaved 8-row blocks would balance better, but contiguous row blocks are what
-     * SURVEY 8(d) specifies for the CPU baseline ("row-block partition"). */
-    pthread_t tid[256];
-    mt_job job[256];
-    const size_t H = p->y;
-    size_t start = 0;
-    int started = 0;
-    for (int t = 0; t < nthreads; t++) {
-        const size_t end = (H * (size_t)(t + 1)) / (size_t)nthreads;
-        job[t].p = p;
-        job[t].objects = objects;
-        job[t].count = count;
-        job[t].mode = mode;
-        job[t].flags = flags;
-        job[t].row0 = start;
-        job[t].rows = end - start;
-        job[t].result = result;
-        start = end;
-        if (pthread_create(&tid[t], NULL, mt_worker, &job[t]) != 0) {
-            mt_worker(&job[t]);
-            tid[t] = 0;
-            continue;
-        }
-        started |= 1;
+    /* Row blocks ("row-block partition"), handed out dynamically: every worker draws the next
+     * block of ORC_MT_BLOCK_ROWS rows from a shared counter, so that rows over dense parts of the scene do not
+     * leave the other threads idle at the end (a static block per thread did: VERDICT r03).  Pixels are
+     * independent, so the frame is the same bytes whatever the schedule. */
+    static pthread_t tid[1024];
+    static char joined[1024];
+    mt_shared job;
+    job.p = p;
+    job.objects = objects;
+    job.count = count;
+    job.mode = mode;
+    job.flags = flags;
+    job.next_row = 0;
+    job.result = result;
+    for (int t = 0; t + 1 < nthreads; t++) {
+        joined[t] = pthread_create(&tid[t], NULL, mt_worker, &job) == 0 ? 1 : 0;
     }
-    (void)started;
-    for (int t = 0; t < nthreads; t++) {
-        if (tid[t]) {
+    mt_worker(&job); /* the caller is the last of the `nthreads` workers (and works alone if no thread could be started) */
+    for (int t = 0; t + 1 < nthreads; t++) {
+        if (joined[t]) {
             pthread_join(tid[t], NULL);
         }
     }

@@ -99,7 +99,11 @@ int orc_trace_pixel(const orc_params* p, const orc_object* const* objects, unsig
 int orc_render_rows(const orc_params* p, const orc_object* const* objects, unsigned count, int mode,
                     size_t row0, size_t rows, int flags, char* result, orc_pixel* pixels);
 
-/* Same, all rows, split over `nthreads` host threads by row blocks. */
+/* Row `row` alone into row_out (x * S bytes, S = 12 or 20 by mode, zero-initialised by the caller). */
+int orc_render_row(const orc_params* p, const orc_object* const* objects, unsigned count, int mode,
+                   size_t row, int flags, char* row_out);
+
+/* Same, all rows, over `nthreads` host threads (1..1024): blocks of 4 rows drawn from a shared counter.  Not reentrant. */
 int orc_render_mt(const orc_params* p, const orc_object* const* objects, unsigned count, int mode,
                   int flags, int nthreads, char* result);
 

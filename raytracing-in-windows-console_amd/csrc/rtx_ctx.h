@@ -79,11 +79,14 @@ struct rtx_ctx {
         size_t cap = 0;              // tiles the buffers hold
         uint64_t last_use = 0;       // ctx->order_clock at the last launch (least recently used set is recycled)
         bool frozen = false;         // a recorded (HIP graph) launch reads the order in use: nothing is derived for this set any more
+        uint32_t frozen_refs = 0;    // ... by this many live graphs (rtx_graph_destroy of the last one releases the set)
+        uint64_t id = 0;             // stable name of the set (the vector's entries move)
         const uint32_t* base = nullptr; // the static XCD-aware order of the launch in hand, or nullptr (rtx_order_tiles sorts per XCD label within it)
         rtxplan::DispatchOrder plan;
     };
     std::vector<TileOrder> tile_orders;
-    uint64_t order_clock = 0;
+    uint64_t order_clock = 0, next_order_id = 1;
+    std::vector<uint64_t> capture_frozen; // ids of the sets the capture in progress has frozen (handed to the graph by rtx_graph_end)
 
     // Coarse-cell lists that outlive a frame (two-level culling): two sets, shared by all render streams, each valid for
     // cameras within the motion budget it was binned with (rtxplan::CellCachePolicy).  A set is (re)built on the render
@@ -114,14 +117,18 @@ struct rtx_ctx {
     uint32_t cell_cap_floor = 0;                // capacity the lists of the current grid are planned with at least
     uint64_t cell_grid_id[3] = {0, 0, 0};       // the grid (and scene generation) the two words above belong to
     uint64_t per_frame_bins = 0;
-    uint32_t* xcd_order = nullptr;              // static dispatch order of a two-level grid: a cell's tiles share an XCD
-    size_t xcd_order_cap = 0;
-    uint64_t xcd_order_key[2] = {0, 0};
+    struct XcdOrder {                           // static dispatch order of a two-level grid: a cell's tiles share an XCD
+        uint32_t* p = nullptr;
+        size_t cap = 0;
+        uint64_t key[2] = {0, 0};               // (tile grid, cell shape)
+        uint64_t last_use = 0;
+    };
+    XcdOrder xcd_orders[4];                     // the grids seen last (least recently used is replaced)
     int64_t opt_cell_reuse = -1;                // -1 auto (on), 0 off: bin per frame as before round 3
     int64_t opt_xcd_order = -1;                 // -1 auto (on for two-level grids), 0 off
     // view-density feedback (rtxplan::ViewDensity): the longest candidate list the trace workgroups of an epoch (8 culling
     // launches) report, copied to the pinned word when the epoch ends and taken as an observation once that copy has landed
-    uint32_t* d_longest = nullptr;              // two words: the epoch being filled, and the one before (being copied / zeroed)
+    uint32_t* d_longest = nullptr;              // three words in rotation: the epoch being filled, the next one (zeroed), the one before (being copied)
     volatile uint32_t* h_longest = nullptr;
     hipEvent_t ev_longest = nullptr;
     bool longest_copy_pending = false;
@@ -141,8 +148,8 @@ struct rtx_ctx {
 
     hipStream_t aux_stream = nullptr; // the balancing passes' stream (created with the first pass)
     double scene_drift = 0.0;        // how far any sphere can have moved since the context was created (rtx_update_objects:
-                                     // |dt| x the largest speed; scene edits add 1e3): dispatch orders go stale with it
-    float max_speed = 0.0f;          // largest |speed| any sphere was given
+                                     // |dt| x the largest |speed x mover|; scene edits add 1e3): dispatch orders go stale with it
+    float max_speed = 0.0f;          // largest |speed * mover| any sphere was given: what a physics step moves it by per unit of dt
     int64_t opt_tile_order = -1;    // -1 = auto (grids of one dispatch round, period 16), 0 = off, k = on: re-derive the order after
                                     // the 1st and 2nd frame of a grid, then every k-th
     int n_cu = 0;                   // compute units of the device

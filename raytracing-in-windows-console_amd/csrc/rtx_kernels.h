@@ -72,10 +72,12 @@ struct KArgs {
     const uint32_t* tile_order;
     uint32_t* tile_cost;
     // View-density feedback for the host (rtx_plan.hpp, ViewDensity), culling kernels: workgroups whose candidate list holds at
-    // least longest_from entries atomicMax its length into longest_list[longest_epoch & 1]; the first workgroup zeroes the
-    // other word, which the launches of the next epoch fill.  nullptr: no feedback.
+    // least longest_from entries atomicMax its length into longest_list[longest_slot] (three words in rotation, slot = epoch
+    // mod 3); the first workgroup zeroes the NEXT slot, which the launches of the next epoch fill -- never the previous one,
+    // whose copy to the host may still be queued on another stream (an epoch only begins once the copy of the epoch before
+    // the last has landed, so the slot being zeroed is always one whose copy is done).  nullptr: no feedback.
     uint32_t* longest_list;
-    uint32_t longest_from, longest_epoch;
+    uint32_t longest_from, longest_slot;
     uint8_t* out;             // records of row out_row_base start here
     uint32_t refine;          // culling kernels: per-wave refinement of the candidate list (dense scenes; nsub <= 2)
     uint32_t compact;         // 1 = RTX_RENDER_COMPACT: out holds one 4-byte pixel word per pixel instead of a record;

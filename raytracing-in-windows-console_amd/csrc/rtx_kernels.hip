@@ -798,8 +798,8 @@ __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KA
     // an ordinary view, none at all in most)
     if (CULL && a.longest_list != nullptr && tid == 0u) {
         const uint32_t len = overflow ? (uint32_t)kListCap : total;
-        if (len >= a.longest_from) atomicMax(a.longest_list + (a.longest_epoch & 1u), len);
-        if (blockIdx.x == 0u && blockIdx.y == 0u) a.longest_list[(a.longest_epoch & 1u) ^ 1u] = 0u;
+        if (len >= a.longest_from) atomicMax(a.longest_list + a.longest_slot, len);
+        if (blockIdx.x == 0u && blockIdx.y == 0u) a.longest_list[a.longest_slot == 2u ? 0u : a.longest_slot + 1u] = 0u;
     }
     lds_barrier(); // list complete, tables visible
     const uint32_t np_vis = (uint32_t)__builtin_amdgcn_readfirstlane(s_nplanes); // planes in the table

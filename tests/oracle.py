@@ -65,6 +65,8 @@ def lib():
         L.orc_render_rows.argtypes = [C.POINTER(Params), PP, C.c_uint, C.c_int, C.c_size_t, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_void_p]
         L.orc_render_rows.restype = C.c_int
+        L.orc_render_row.argtypes = [C.POINTER(Params), PP, C.c_uint, C.c_int, C.c_size_t, C.c_int, C.c_void_p]
+        L.orc_render_row.restype = C.c_int
         L.orc_render_mt.argtypes = [C.POINTER(Params), PP, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_render_mt.restype = C.c_int
         L.orc_minimize.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
@@ -192,6 +194,17 @@ def render(params, scene, mode, flags=0, threads=1, want_pixels=False, row0=0, r
     if rc != 0:
         raise ValueError("oracle: invalid rendering mode %r" % (mode,))
     return (buf, px.reshape(H, W)) if want_pixels else buf
+
+
+def render_row(params, scene, mode, row, flags=0):
+    """Row `row` of the frame alone: W*S bytes (S = 12 or 20 by mode), without a frame-sized buffer."""
+    W = int(params.x)
+    S = 20 if mode >= RGB_ASCII else 12
+    buf = np.zeros(W * S, dtype=np.uint8)
+    rc = lib().orc_render_row(C.byref(params), scene.ptrs(), scene.count, mode, row, flags, buf.ctypes.data)
+    if rc != 0:
+        raise ValueError("oracle: invalid rendering mode %r" % (mode,))
+    return buf
 
 
 def minimize(mode, buf, w, h):

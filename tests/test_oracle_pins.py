@@ -103,3 +103,20 @@ def test_digit_encoder_is_plain_decimal_with_nul_padding():
         want = np.stack([np.where(val >= 100, val // 100 + 48, 0), np.where(val >= 10, (val // 10) % 10 + 48, 0),
                          val % 10 + 48], axis=1)
         assert np.array_equal(d, want)
+
+
+def test_threaded_and_single_row_forms_equal_the_plain_loop():
+    """orc_render_mt (rows handed out in 4-row blocks from a shared counter: what bench.py's cpu_baseline times) and
+    orc_render_row (one row into a buffer of its own: what the GPU fuzz tests compare sampled rows with) are the same
+    per-pixel loop as orc_render_rows, so the bytes are the same whatever the schedule."""
+    sc = O.Scene.reference_default()
+    p = O.camera_params(400, 150)
+    for mode in (O.BIT_ASCII, O.RGB_ASCII, O.RGB_NORMALS):
+        S = 20 if mode >= O.RGB_ASCII else 12
+        full = O.render(p, sc, mode)
+        for threads in (2, 7, 64):
+            assert np.array_equal(O.render(p, sc, mode, threads=threads), full)
+        for r in (0, 1, 77, 149):
+            assert np.array_equal(O.render_row(p, sc, mode, r), full[r * 400 * S:(r + 1) * 400 * S])
+    with pytest.raises(ValueError):
+        O.render(p, sc, 9, threads=4)

@@ -8,7 +8,7 @@ TAG=$1; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-moving-view --frames-in-flight 1 $*"
+ARGS="--steps 30 --warmup 5 --no-cpu-baseline --no-moving-view --no-side-legs --frames-in-flight 1 $*"
 run() { # name, rocprof flags...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }

@@ -118,6 +118,8 @@ enum rtx_option {
                                * from the camera of the first launch after a scene edit), kept in step by rtx_update_objects: the spheres
                                * of a coarse cell are then neighbours in memory (config 5: a quarter of the lines per launch).  Speed
                                * only; ties are still broken by creation order.  Scenes from 256 spheres.  -1 auto (on), 0 off, 1 on */
+    RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */
+    RTX_OPT_GROUP_WIRE = 13,  /* device groups: enum rtx_group_wire -- what travels: compact pixel words (default) or records */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
                                * stays off) */
@@ -133,6 +135,10 @@ enum rtx_stat {
     RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a live recorded graph reads (kept as they are until it is destroyed) */
     RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
+    RTX_STAT_GROUP_SIZE = 110,      /* logical ranks of the device group this context is the root of (1: a plain context) */
+    RTX_STAT_GROUP_EXCHANGE = 111,  /* the exchange the last sharded frame used: RTX_EXCHANGE_PEER_COPY or RTX_EXCHANGE_RCCL (0: none yet) */
+    RTX_STAT_GROUP_GATHERS = 112,   /* sharded frames gathered so far */
+    RTX_STAT_GROUP_BYTES = 113,     /* bytes the last gather moved between devices */
     RTX_STAT_CELL_CAPACITY_FLOOR = 107 /* entries per cell list the current grid is planned with at least (0: the default capacity has
                                      * sufficed); grown from the longest list the binning passes report */
 };
@@ -172,6 +178,40 @@ typedef struct rtx_segment {
  * PrintMachine.cpp:140) and the scene store.  `device` is the HIP device ordinal. */
 int rtx_create(int device, size_t max_w, size_t max_h, rtx_ctx** out);
 void rtx_destroy(rtx_ctx* ctx);
+
+/* ---- device groups: the `rtx_create(ndev, ...)` of SURVEY.md 8(b) / 8(e).  One context that renders on ndev devices of this
+ * process: the frame shards by pixel rows -- logical rank g (device devices[g]; NULL = devices 0 .. ndev-1) traces rows
+ * [g*H/ndev, (g+1)*H/ndev) with the global row index in ray generation (RayTracing.cu:12,16) -- and the slabs are gathered
+ * into the device memory of rank 0 (the root, devices[0]) by RCCL (ncclCommInitAll; grouped ncclSend / ncclRecv over xGMI,
+ * ragged last slab) or hipMemcpyPeerAsync; the root then holds the byte-identical 20*W*H buffer a one-device rtx_render
+ * produces (a block of rows is one contiguous byte range, RayTracing.cu:238,457).  The returned context IS the group: every
+ * entry point takes it like any other context, and on it
+ *   rtx_scene_* / rtx_update_objects / rtx_set_option   apply to every rank's replica of the scene (<= 6.8 MB, replicated),
+ *   rtx_render, rtx_update, rtx_update_begin / _end      trace sharded and deliver on the root exactly what they deliver on one
+ *                                                        device (frame buffer, minimised stream),
+ *   rtx_render_rows, rtx_submit_*, rtx_expand, rtx_minimize, graphs   act on the root's device alone (caller's buffers there),
+ *   rtx_destroy                                          releases the whole group.
+ * The reference's single consumer, RayTracingManager::Update (RayTracingManager.cu:76-154, hand-off at :150), therefore
+ * runs unchanged over N GPUs: include/rtx_compat.hpp takes the device list from RTX_DEVICES or Device::set_devices().
+ * A device may appear more than once (several logical ranks on one GPU: how a one-GPU box walks N = 4 or 8; the gather is
+ * then peer / same-device copies -- an RCCL communicator needs one rank per GPU).  ndev in [1, 64]. */
+int rtx_group_create(int ndev, const int* devices, size_t max_w, size_t max_h, rtx_ctx** out);
+int rtx_group_size(const rtx_ctx* ctx);                      /* logical ranks (1 for a plain context) */
+rtx_ctx* rtx_group_member(rtx_ctx* ctx, int rank);           /* rank's member context, for reading (statistics, kernel names); rank 0 = ctx */
+int rtx_group_rows(const rtx_ctx* ctx, size_t h, int rank, size_t* row0, size_t* rows); /* the rows rank traces of an h-row frame */
+const char* rtx_group_exchange_note(const rtx_ctx* ctx);     /* one line: how the last gather moved its bytes, or why RCCL is not in use */
+
+enum rtx_group_exchange {
+    RTX_EXCHANGE_AUTO = 0,      /* RCCL where the list names ndev > 1 distinct devices and librccl loads and initialises; else peer copies */
+    RTX_EXCHANGE_PEER_COPY = 1, /* hipMemcpyPeerAsync on the sender's stream, ordered by events */
+    RTX_EXCHANGE_RCCL = 2,      /* grouped ncclSend / ncclRecv (distinct devices only) */
+    RTX_EXCHANGE_RCCL_ALL = 3   /* ... with the root's own slab sent to itself as well: walks the RCCL path at ndev = 1 (tests) */
+};
+enum rtx_group_wire {
+    RTX_WIRE_AUTO = 0,    /* compact */
+    RTX_WIRE_RECORDS = 1, /* the 12 / 20-byte records travel and land at their place in the frame */
+    RTX_WIRE_COMPACT = 2  /* 4-byte pixel words travel (RTX_RENDER_COMPACT); the root writes the records (rtx_expand) or minimises from the words */
+};
 
 /* Text of the last error on this context (or of the last failed rtx_create when ctx is NULL). */
 const char* rtx_last_error(const rtx_ctx* ctx);

@@ -30,6 +30,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -137,7 +138,10 @@ inline void check(rtx_ctx* ctx, int status, const char* what)
     }
 }
 
-// One device context per process, like the reference's single default device.
+// One device context per process, like the reference's single default device -- or one device GROUP: with a
+// device list (Device::set_devices({0, 1, 2, 3}) before the first use, or RTX_DEVICES=0,1,2,3 in the environment) the same
+// context renders every frame row-sharded over those GPUs and assembles it on the first (rtx_group_create, rtx.h), and
+// Engine3D::Render-style code -- Scene3D::CreateSphere, RayTracingManager::Update -- runs unchanged on top.
 struct Device {
     static rtx_ctx*& slot()
     {
@@ -149,13 +153,37 @@ struct Device {
         static int dev = 0;
         return dev;
     }
+    static std::vector<int>& devices()
+    {
+        static std::vector<int> list;
+        return list;
+    }
+    static void set_devices(const std::vector<int>& list) { devices() = list; }
+    static std::vector<int> devices_from_environment()
+    {
+        std::vector<int> list;
+        const char* env = std::getenv("RTX_DEVICES");
+        if (!env) return list;
+        const char* p = env;
+        while (*p) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            list.push_back((int)v);
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
+        }
+        return list;
+    }
     static rtx_ctx* get(size_t max_w, size_t max_h)
     {
         rtx_ctx*& ctx = slot();
         if (!ctx) {
-            const int rc = rtx_create(ordinal(), max_w, max_h, &ctx);
+            std::vector<int> list = devices().empty() ? devices_from_environment() : devices();
+            const int rc = list.empty() ? rtx_create(ordinal(), max_w, max_h, &ctx)
+                                        : rtx_group_create((int)list.size(), list.data(), max_w, max_h, &ctx);
             if (rc != RTX_OK) {
-                throw std::runtime_error(std::string("rtx_create: ") + rtx_last_error(nullptr));
+                throw std::runtime_error(std::string(list.empty() ? "rtx_create: " : "rtx_group_create: ") + rtx_last_error(nullptr));
             }
         }
         return ctx;

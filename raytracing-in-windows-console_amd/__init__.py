@@ -26,6 +26,10 @@ OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_D
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
 OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER, OPT_VIEW_ADAPT, OPT_SORTED_STORE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN, STAT_CELL_CAPACITY_FLOOR, STAT_VIEW_DENSE, STAT_DENSITY_SWITCHES = 101, 102, 103, 104, 105, 106, 107, 108, 109
+OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE = 12, 13
+STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113
+EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, EXCHANGE_RCCL_ALL = 0, 1, 2, 3
+WIRE_AUTO, WIRE_RECORDS, WIRE_COMPACT = 0, 1, 2
 RENDER_ZERO_TAIL = 1
 RENDER_COMPACT = 2
 RENDER_VALUES = 4
@@ -53,6 +57,11 @@ class Params(C.Structure):
 _P = C.c_void_p
 _SIGNATURES = [
     ("rtx_create", C.c_int, [C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    ("rtx_group_create", C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_size_t, C.c_size_t, C.POINTER(_P)]),
+    ("rtx_group_size", C.c_int, [_P]),
+    ("rtx_group_member", _P, [_P, C.c_int]),
+    ("rtx_group_rows", C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    ("rtx_group_exchange_note", C.c_char_p, [_P]),
     ("rtx_destroy", None, [_P]),
     ("rtx_last_error", C.c_char_p, [_P]),
     ("rtx_version", C.c_char_p, []),
@@ -168,12 +177,43 @@ def config_inputs(name):
 class Context:
     """One rtx_ctx: what RayTracingManager + Scene3D own on the device (RayTracingManager.cu:53-74)."""
 
-    def __init__(self, max_w, max_h, device=0):
+    def __init__(self, max_w, max_h, device=0, devices=None):
+        """devices: a list of HIP device ordinals -> a device group (rtx_group_create): the frame shards by rows over them,
+        one logical rank per entry (an ordinal may repeat), and is assembled on devices[0]."""
         self._h = _P()
-        rc = lib().rtx_create(device, max_w, max_h, C.byref(self._h))
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = lib().rtx_group_create(len(devices), devs, max_w, max_h, C.byref(self._h))
+        else:
+            rc = lib().rtx_create(device, max_w, max_h, C.byref(self._h))
         if rc != OK:
             raise RtxError(rc, (lib().rtx_last_error(None) or b"").decode())
         self.max_w, self.max_h = max_w, max_h
+
+    # -- device groups
+    @property
+    def group_size(self):
+        return lib().rtx_group_size(self._h)
+
+    def group_rows(self, h, rank):
+        r0, n = C.c_size_t(), C.c_size_t()
+        self._check(lib().rtx_group_rows(self._h, h, rank, C.byref(r0), C.byref(n)))
+        return r0.value, n.value
+
+    @property
+    def exchange_note(self):
+        return (lib().rtx_group_exchange_note(self._h) or b"").decode()
+
+    def member_kernel(self, rank):
+        """Name of the kernel logical rank `rank` launched last."""
+        m = lib().rtx_group_member(self._h, rank)
+        return (lib().rtx_last_kernel_name(m) or b"").decode() if m else ""
+
+    def member_option(self, rank, opt):
+        m = lib().rtx_group_member(self._h, rank)
+        v = C.c_int64(0)
+        self._check(lib().rtx_get_option(m, opt, C.byref(v)))
+        return v.value
 
     def close(self):
         if self._h:

@@ -19,8 +19,11 @@ struct HostPlane {
     float4 a, b, c, od;
 };
 
+struct rtx_group; // rtx_group.cpp: the device group a context is the root of
+
 struct rtx_ctx {
     int device = 0;
+    rtx_group* group = nullptr;     // not null: this context is the root of a device group (rtx_group_create)
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     size_t max_w = 0, max_h = 0, capacity = 0;
@@ -190,6 +193,10 @@ int rtx_hip_fail(rtx_ctx* ctx, hipError_t e, const char* what);
 int rtx_sync_scene(rtx_ctx* ctx);
 void rtx_scene_edited(rtx_ctx* ctx);
 int rtx_sort_scene(rtx_ctx* ctx, const float origin[3]); // rtx_post.hip
+// the zero-fill bookkeeping of the context's own frame buffer for a frame of `mode` whose records something other than
+// rtx_render_rows is about to write there (a group's gathered slabs, its expanded words), on the context's stream
+extern "C" int rtx_frame_zero_semantics(rtx_ctx* ctx, int mode, uint64_t W, uint64_t H, unsigned flags); // (hidden: not part of the ABI)
+bool rtx_group_stat(const rtx_ctx* ctx, int option, int64_t* value); // rtx_group.cpp
 
 #define RTX_HIP(ctx, call)                          \
     do {                                            \

@@ -2,6 +2,7 @@
 // UpdateObjects (RayTracingManager.cu:10-44, 89-107) and Minimize (RayTracingManager.cu:167-319),
 // plus rtx_update, the whole of Update in one call.
 #include "rtx_ctx.h"
+#include "rtx_group.h"
 #include "rtx_device.hpp"
 
 #include <algorithm>
@@ -459,7 +460,7 @@ int rtx_update_objects(rtx_ctx* ctx, double dt)
     } else {
         ctx->scene_drift += step + 2.0e-6; // (+ the rounding of y to float: half an ulp of 10)
     }
-    return RTX_OK;
+    return ctx->group ? rtxgroup::update_objects(ctx, dt) : RTX_OK; // every rank steps its replica: the same arithmetic on the same values
 }
 
 void* rtx_minimized_device_ptr(rtx_ctx* ctx) { return ctx ? ctx->d_min : nullptr; }
@@ -579,7 +580,11 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     if (mode == RTX_SDL) {
         RTX_HIP(ctx, hipMemsetAsync(sl.d_frame, 0, 20 * w * h, ctx->stream));
     }
-    if ((rc = rtx_render_rows(ctx, params, mode, 0, h, sl.d_frame, 0, ctx->stream, rgb ? RTX_RENDER_DEFAULT : RTX_RENDER_ZERO_TAIL)) != RTX_OK) return rc;
+    if (ctx->group) {
+        if ((rc = rtxgroup::render_frame(ctx, params, mode, sl.d_frame, rgb ? RTX_RENDER_DEFAULT : RTX_RENDER_ZERO_TAIL)) != RTX_OK) return rc;
+    } else if ((rc = rtx_render_rows(ctx, params, mode, 0, h, sl.d_frame, 0, ctx->stream, rgb ? RTX_RENDER_DEFAULT : RTX_RENDER_ZERO_TAIL)) != RTX_OK) {
+        return rc;
+    }
     uint64_t* d_total = nullptr;
     if ((rc = launch_minimize(ctx, sl.d_scan, mode, w, h, sl.d_frame, sl.d_min, &d_total)) != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemcpyAsync(sl.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -51,6 +51,26 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     assert e.value.status == R.ERR_NO_DEVICE
 
 
+def test_device_group_without_a_gpu_fails_the_same_way_and_validates_its_arguments():
+    """rtx_group_create (the row-sharded frame behind the ABI): no device -> RTX_ERR_NO_DEVICE, never a CPU path; a device
+    count outside [1, 64] is refused before anything is created; librccl is not mapped by loading the library (it is
+    opened on the first exchange that wants it)."""
+    import ctypes as C
+    import torch
+    R = U.pkg()
+    h = C.c_void_p()
+    assert R.lib().rtx_group_create(0, None, 64, 64, C.byref(h)) == R.ERR_INVALID_ARGUMENT and not h.value
+    assert R.lib().rtx_group_create(65, None, 64, 64, C.byref(h)) == R.ERR_INVALID_ARGUMENT and not h.value
+    assert b"ndev" in R.lib().rtx_last_error(None)
+    assert R.lib().rtx_group_size(None) == 0
+    import subprocess
+    assert "rccl" not in subprocess.check_output(["ldd", R.LIB_PATH]).decode()
+    if not torch.cuda.is_available():
+        with pytest.raises(R.RtxError) as e:
+            R.Context(64, 64, devices=[0, 0])
+        assert e.value.status == R.ERR_NO_DEVICE
+
+
 def test_product_never_links_the_oracle():
     R = U.pkg()
     import subprocess

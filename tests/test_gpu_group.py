@@ -1,0 +1,208 @@
+"""Device groups (rtx_group_create, include/rtx.h): the row-sharded frame BEHIND the C ABI -- SURVEY.md 8(b) `rtx_create(ndev, ...)`,
+8(e) "single process, one stream per device, ncclCommInitAll".  The reference's one consumer is RayTracingManager::Update
+(RayTracingManager.cu:76-154, hand-off at :150) and rows are contiguous byte ranges of the frame (RayTracing.cu:238,457); a group
+context must deliver on its root, byte for byte, what one device delivers.
+
+This box has ONE GPU: groups of 4 and 8 logical ranks are built from a device list that repeats device 0 (every rank its own
+member context, scene replica, stream and slab; the gather is hipMemcpyPeerAsync between buffers of one device), and the RCCL
+form is walked at ndev = 1 with RTX_EXCHANGE_RCCL_ALL (the root's own slab is sent to itself through ncclSend / ncclRecv).  What a
+real 8-GPU node adds is distinct devices under the same code; that is the driver's SCALE run."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def R():
+    return U.pkg()
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("ranks,wire", [(4, "compact"), (8, "compact"), (8, "records"), (3, "records")])
+def test_group_frame_of_config_2_is_the_golden_frame(R, ranks, wire):
+    """rtx_render on a group: rank g traces rows [g H / N, (g+1) H / N) with the global row index, the slabs are gathered on the
+    root; the root's frame buffer then holds the golden C2 frame (oracle-generated), whole 20*W*H buffer, both wire formats."""
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0] * ranks) as c:
+        assert c.group_size == ranks and c.get_option(R.STAT_GROUP_SIZE) == ranks
+        assert [c.group_rows(H, r) for r in range(ranks)] == [(H * r // ranks, H * (r + 1) // ranks - H * r // ranks) for r in range(ranks)]
+        c.set_option(R.OPT_GROUP_WIRE, R.WIRE_COMPACT if wire == "compact" else R.WIRE_RECORDS)
+        c.set_scene(sph, pl)
+        for mode in (R.RGB_ASCII, R.BIT_ASCII, R.RGB_ASCII):      # (8-bit after RGB: the tail must be NUL again)
+            got = c.render_to_host(p, mode)
+            assert _sha(got) == gold["C2_%s" % R.MODE_NAMES[mode]]["frame_sha256"], (R.MODE_NAMES[mode], wire)
+        assert c.get_option(R.STAT_GROUP_GATHERS) == 3
+        S = 4 if wire == "compact" else 20
+        assert c.get_option(R.STAT_GROUP_BYTES) == (H - H // ranks) * W * S     # every slab but the root's crossed
+        assert c.get_option(R.STAT_GROUP_EXCHANGE) == R.EXCHANGE_PEER_COPY and "repeats a device" in c.exchange_note
+        for r in range(ranks):
+            assert "rtx_trace" in c.member_kernel(r)               # every rank launched a trace kernel of its own
+
+
+def test_group_of_eight_renders_config_4_as_8_slabs_of_540_rows(R):
+    """SURVEY 8(e)'s case: 7680x4320 over 8 ranks, 540 rows = 82 944 000 bytes of records each."""
+    gold = U.load_golden()["C4_RGB_ASCII"]
+    p, sph, pl = R.config_inputs("C4")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0] * 8) as c:
+        c.set_scene(sph, pl)
+        assert all(c.group_rows(H, r) == (540 * r, 540) for r in range(8))
+        for wire in (R.WIRE_COMPACT, R.WIRE_RECORDS):
+            c.set_option(R.OPT_GROUP_WIRE, wire)
+            assert O.fnv1a64(c.render_to_host(p, R.RGB_ASCII)) == gold["frame_fnv1a64"]
+        assert c.get_option(R.STAT_GROUP_BYTES) == 7 * 540 * W * 20
+
+
+@pytest.mark.parametrize("ranks,W,H", [(7, 400, 150), (5, 97, 41), (8, 64, 3), (2, 333, 1), (16, 320, 180)])
+def test_ragged_and_empty_slabs_against_the_oracle(R, ranks, W, H):
+    """H not a multiple of N (ragged slabs), more ranks than rows (empty slabs), every mode, both wires: the frame and the
+    minimised stream of rtx_update equal the oracle's."""
+    sc = O.Scene.reference_default()
+    p = R.camera_params(W, H)
+    with R.Context(W, H, devices=[0] * ranks) as c:
+        c.set_reference_default_scene()
+        for wire in (R.WIRE_COMPACT, R.WIRE_RECORDS):
+            c.set_option(R.OPT_GROUP_WIRE, wire)
+            for mode in range(6):
+                want = O.render(U.oracle_params(p), sc, mode)
+                got = c.render_to_host(p, mode)
+                assert np.array_equal(got, want), (R.MODE_NAMES[mode], wire, U.first_diff(got, want, 20 if mode >= 2 else 12, W))
+                assert np.array_equal(c.update(p, mode), O.minimize(mode, want, W, H)), (R.MODE_NAMES[mode], wire)
+
+
+def test_update_through_the_group_is_the_single_device_stream(R):
+    """RayTracingManager::Update's sequence (physics, trace, minimise, hand-off) through a group of 4: scene edits, sphere motion
+    and every physics step reach all replicas, so the stream stays byte-equal to a single-device context's (and the oracle's)
+    frame after frame; the pipelined form (rtx_update_begin / _end) as well."""
+    W, H, n = 640, 360, 1500
+    rng = np.random.default_rng(11)
+    p = R.camera_params(W, H)
+    sph, pl = R.synth_scene(9, n, 1, p.element1, p.element2)
+    speeds = (rng.integers(50, 400, n) / 100.0).astype(np.float32)
+    sc = O.Scene.from_arrays(sph, pl)
+    with R.Context(W, H, devices=[0, 0, 0, 0]) as g, R.Context(W, H) as one:
+        for c in (g, one):
+            c.set_scene(sph, pl)
+            for i in range(0, n, 3):
+                c.set_sphere_motion(i, 1 if i % 2 else -1, float(speeds[i]))
+        for i in range(0, n, 3):
+            sc.objects()[i].speed = float(speeds[i])
+            sc.objects()[i].mover = 1 if i % 2 else -1
+        assert g.object_count == one.object_count == n + 1
+        for f in range(6):
+            mode = (R.RGB_ASCII, R.BIT_ASCII, R.RGB_PIXEL)[f % 3]
+            a = g.update(p, mode, dt=0.05, run_physics=True).copy()
+            b = one.update(p, mode, dt=0.05, run_physics=True).copy()
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, 0.05)
+            assert np.array_equal(a, b), f
+            if f in (0, 5):
+                assert np.array_equal(a, O.minimize(mode, O.render(U.oracle_params(p), sc, mode, threads=8), W, H)), f
+            if f == 2:   # an edit in the middle: the new sphere lands in every replica, at the same creation index
+                for c in (g, one):
+                    assert c.add_sphere(3.0, (0.0, 0.0, 30.0), (200.0, 100.0, 50.0)) == n + 1
+                sc.add_sphere(3.0, (0.0, 0.0, 30.0), (200.0, 100.0, 50.0))
+        # every replica holds the same sphere positions as the single device
+        for i in (0, 3, 999, n + 1):
+            t0, v0 = one.get_object(i)
+            assert t0 == g.get_object(i)[0] and np.array_equal(v0, g.get_object(i)[1])
+        # pipelined Update
+        hb = [g.host_alloc(20 * W * H) for _ in range(2)]
+        tick = []
+        outs = []
+        for f in range(4):
+            if len(tick) == 2:
+                t, k = tick.pop(0)
+                outs.append(hb[k][1][:g.update_end(t)].copy())
+            tick.append((g.update_begin(p, R.RGB_ASCII, hb[f % 2][0], dt=0.05, run_physics=True), f % 2))
+        while tick:
+            t, k = tick.pop(0)
+            outs.append(hb[k][1][:g.update_end(t)].copy())
+        for f in range(4):
+            assert np.array_equal(outs[f], one.update(p, R.RGB_ASCII, dt=0.05, run_physics=True)), f
+        for ptr, _ in hb:
+            g.host_free(ptr)
+
+
+def test_rccl_exchange_at_one_device_and_the_fallbacks(R):
+    """The RCCL form of the gather, walked on the one GPU this box has: RTX_EXCHANGE_RCCL_ALL sends the root's own slab to
+    itself (ncclCommInitAll over [0], grouped ncclSend / ncclRecv on the root's stream) -- communicator set-up, the group call
+    and the stream ordering are the code an 8-GPU node runs.  A device list that repeats a device cannot have a communicator
+    (one rank per GPU): asking for RCCL there is refused, AUTO takes peer copies."""
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0]) as c:
+        c.set_scene(sph, pl)
+        c.set_option(R.OPT_GROUP_EXCHANGE, R.EXCHANGE_RCCL_ALL)
+        for wire in (R.WIRE_COMPACT, R.WIRE_RECORDS):
+            c.set_option(R.OPT_GROUP_WIRE, wire)
+            for mode in (R.RGB_ASCII, R.BIT_ASCII):
+                assert _sha(c.render_to_host(p, mode)) == gold["C2_%s" % R.MODE_NAMES[mode]]["frame_sha256"], (wire, mode)
+                assert c.get_option(R.STAT_GROUP_EXCHANGE) == R.EXCHANGE_RCCL, c.exchange_note
+        assert c.get_option(R.STAT_GROUP_BYTES) == H * W * 12
+        got = c.update(p, R.RGB_ASCII)
+        assert len(got) == gold["C2_RGB_ASCII"]["minimized_bytes"] and O.fnv1a64(got) == gold["C2_RGB_ASCII"]["minimized_fnv1a64"]
+    with R.Context(64, 32, devices=[0, 0]) as c:
+        with pytest.raises(R.RtxError):
+            c.set_option(R.OPT_GROUP_EXCHANGE, R.EXCHANGE_RCCL)
+        c.set_option(R.OPT_GROUP_EXCHANGE, R.EXCHANGE_PEER_COPY)
+    with R.Context(64, 32) as c:      # a plain context is a group of one, without the group options
+        assert c.group_size == 1 and c.get_option(R.STAT_GROUP_SIZE) == 1
+        with pytest.raises(R.RtxError):
+            c.set_option(R.OPT_GROUP_WIRE, R.WIRE_RECORDS)
+
+
+def test_options_reach_every_rank_and_errors_name_the_rank(R):
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0, 0, 0]) as c:
+        c.set_scene(sph, pl)
+        c.set_option(R.OPT_KERNEL, R.KERNEL_BRUTE)
+        assert all(c.member_option(r, R.OPT_KERNEL) == R.KERNEL_BRUTE for r in range(3))
+        brute = c.render_to_host(p, R.RGB_ASCII)
+        assert all("false" in c.member_kernel(r) for r in range(3)), [c.member_kernel(r) for r in range(3)]
+        c.set_option(R.OPT_KERNEL, R.KERNEL_AUTO)
+        assert np.array_equal(brute, c.render_to_host(p, R.RGB_ASCII))
+        big = R.camera_params(W + 1, H)
+        with pytest.raises(R.RtxError) as e:
+            c.render(big, R.RGB_ASCII)
+        assert e.value.status == R.ERR_TOO_LARGE
+
+
+def test_reference_api_surface_over_a_group(R, tmp_path):
+    """examples/headless_engine.cpp -- Engine3D::Start / Render through RayTracingManager, Scene3D, Camera3D, PrintMachine of
+    include/rtx_compat.hpp, unchanged -- with RTX_DEVICES=0,0,0,0 in the environment: the facade creates a device group, and the
+    back buffer is what the same binary produces on one device (and what the oracle's Update sequence produces)."""
+    exe = os.path.join(R.PKG_DIR, "headless_engine")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for mode, frames, dt in ((R.BIT_ASCII, 3, 0.05), (R.RGB_ASCII, 2, 0.25)):
+        outs = []
+        for devs in (None, "0,0,0,0", "0"):
+            out = tmp_path / ("frame_%s.bin" % (devs or "single").replace(",", ""))
+            env = dict(os.environ)
+            env.pop("RTX_DEVICES", None)
+            if devs:
+                env["RTX_DEVICES"] = devs
+            subprocess.check_call([exe, "400", "150", str(frames), str(mode), str(dt), str(out)], env=env)
+            outs.append(np.fromfile(out, dtype=np.uint8))
+        sc = O.Scene.reference_default()
+        p = O.camera_params(400, 150)
+        for _ in range(frames):
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, dt)
+            frame = O.render(p, sc, mode)
+        want = O.minimize(mode, frame, 400, 150)
+        for got in outs:
+            assert np.array_equal(got, want)

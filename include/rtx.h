@@ -118,6 +118,10 @@ enum rtx_option {
                                * from the camera of the first launch after a scene edit), kept in step by rtx_update_objects: the spheres
                                * of a coarse cell are then neighbours in memory (config 5: a quarter of the lines per launch).  Speed
                                * only; ties are still broken by creation order.  Scenes from 256 spheres.  -1 auto (on), 0 off, 1 on */
+    RTX_OPT_BATCH = 14,       /* rtx_submit_slabs: consecutive slabs on ONE stream are traced by one launch (up to 16 frames' rows per launch; the
+                               * frames' cameras and output buffers travel in the kernel arguments), instead of a launch each -- a rank's slab of
+                               * a sharded 1080p frame is 255 workgroups, far too few to fill 256 CUs.  Taken where the plan has neither
+                               * two-level culling nor per-wave refinement and the frames differ in camera only.  -1 auto (on), 0 off, 1 on */
     RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */
     RTX_OPT_GROUP_WIRE = 13,  /* device groups: enum rtx_group_wire -- what travels: compact pixel words (default) or records */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
@@ -135,6 +139,7 @@ enum rtx_stat {
     RTX_STAT_ORDERS_FROZEN = 106,   /* dispatch orders a live recorded graph reads (kept as they are until it is destroyed) */
     RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
+    RTX_STAT_BATCHED_LAUNCHES = 114, /* launches that rendered several frames' slabs at once (RTX_OPT_BATCH) */
     RTX_STAT_GROUP_SIZE = 110,      /* logical ranks of the device group this context is the root of (1: a plain context) */
     RTX_STAT_GROUP_EXCHANGE = 111,  /* the exchange the last sharded frame used: RTX_EXCHANGE_PEER_COPY or RTX_EXCHANGE_RCCL (0: none yet) */
     RTX_STAT_GROUP_GATHERS = 112,   /* sharded frames gathered so far */
@@ -263,7 +268,7 @@ int rtx_submit_frames(rtx_ctx* ctx, size_t n, const rtx_params* params, int mode
 
 /* The row-sharded form of rtx_submit_frames (one rank's share of n consecutive frames in the multi-GPU loop,
  * SURVEY.md 8(e)): rows [row0, row0+rows) of frame i are traced with params[i] into d_outs[i], whose first byte
- * is row out_row_base, on streams[i].  If `after` (a hipStream_t) is not NULL the n slabs are ordered after
+ * is row out_row_base, on streams[i] (consecutive slabs given the SAME stream are traced by one launch, RTX_OPT_BATCH).  If `after` (a hipStream_t) is not NULL the n slabs are ordered after
  * everything queued on `after` so far, and `after` is made to wait for all of them (event fork/join inside the
  * call), so that the caller can queue the exchange of the slabs on `after` right away.  `flags` as for
  * rtx_render_rows (RTX_RENDER_COMPACT: d_outs[i] receives pixel words).  No reference

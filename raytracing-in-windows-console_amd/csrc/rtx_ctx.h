@@ -84,6 +84,7 @@ struct rtx_ctx {
         bool frozen = false;         // a recorded (HIP graph) launch reads the order in use: nothing is derived for this set any more
         uint32_t frozen_refs = 0;    // ... by this many live graphs (rtx_graph_destroy of the last one releases the set)
         uint64_t id = 0;             // stable name of the set (the vector's entries move)
+        bool batch = false;          // the set of a batched launch (rtx_trace_batch): plain heaviest first, nothing dealt
         const uint32_t* base = nullptr; // the static XCD-aware order of the launch in hand, or nullptr (rtx_order_tiles sorts per XCD label within it)
         rtxplan::DispatchOrder plan;
     };
@@ -153,6 +154,8 @@ struct rtx_ctx {
     double scene_drift = 0.0;        // how far any sphere can have moved since the context was created (rtx_update_objects:
                                      // |dt| x the largest |speed x mover|; scene edits add 1e3): dispatch orders go stale with it
     float max_speed = 0.0f;          // largest |speed * mover| any sphere was given: what a physics step moves it by per unit of dt
+    int64_t opt_batch = -1;         // -1 auto (on), 0 off: rtx_submit_slabs renders consecutive slabs of one stream with one launch
+    uint64_t stat_batched_launches = 0;
     int64_t opt_tile_order = -1;    // -1 = auto (grids of one dispatch round, period 16), 0 = off, k = on: re-derive the order after
                                     // the 1st and 2nd frame of a grid, then every k-th
     int n_cu = 0;                   // compute units of the device

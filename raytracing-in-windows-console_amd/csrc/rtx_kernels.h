@@ -89,9 +89,31 @@ struct KArgs {
     float edge_up_p[3], edge_up_q[3], edge_right_p[3], edge_right_q[3];
     float edge_pp, edge_qrqr, edge_qcqc;
     float edge_fwd[3];
+    // batched launches (rtx_trace_batch, KBatch): frames in the launch (0: a plain launch), the tile grid of ONE frame
+    uint32_t batch_n, batch_gx, batch_gy;
 #define RTX_X_SECTION_KARGS
 #include "rtx_experiment.inc"
 #undef RTX_X_SECTION_KARGS
+};
+
+// A batched trace launch (rtx_trace_batch): ONE grid renders the same rows of up to kMaxBatch frames -- a rank's slab of every
+// frame of a round in the row-sharded loop, where a single slab (255 workgroups for 135 rows of 1080p) is far too small to fill
+// 256 CUs.  What differs from frame to frame travels beside KArgs in the kernel arguments themselves (no upload, recordable in a
+// HIP graph as is): camera matrix and position, the culling pyramids' edge basis of that camera, the output buffer.  Frame size,
+// projection scalars, far distance, rows, scene and plan are the launch's.  Workgroup b renders tile position b / n of frame
+// b % n: the n copies of a tile are neighbours in dispatch order, so that with the tiles sorted heaviest first every CU's share
+// (blocks c, c + n_cu, ...) is a stratified sample of the cost distribution.
+constexpr int kMaxBatch = 16;
+struct KFrame {
+    float m[12];
+    float ox, oy, oz;
+    float edge_up_p[3], edge_up_q[3], edge_right_p[3], edge_right_q[3];
+    float edge_pp, edge_qrqr, edge_qcqc;
+    float edge_fwd[3];
+    uint8_t* out;
+};
+struct KBatch {
+    KFrame f[kMaxBatch];
 };
 
 // Arguments of rtx_expand_words (compact pixel words -> records), by value.
@@ -113,6 +135,8 @@ int rtx_k_launch_expand(const ExpandArgs* e, int mode, unsigned blocks, void* st
 // Launches the trace kernel for `mode`; returns the kernel's name (NULL for an invalid mode) and
 // the hipGetLastError() value in *hip_error.
 const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, void* stream, int* hip_error);
+// The batched form (culling kernels without per-wave refinement, records or compact words): a->batch_n frames of kb in one launch.
+const char* rtx_k_launch_trace_batch(const KArgs* a, const KBatch* kb, int mode, void* stream, int* hip_error);
 int rtx_k_launch_bin_cells(const KArgs* a, unsigned splits, void* stream);
 int rtx_k_launch_zero(void* p, size_t bytes, void* stream);
 // tile_cost[n_tiles] (grid gx wide) -> tile_order[n_tiles], heaviest first, dealt over n_cu compute units so that the

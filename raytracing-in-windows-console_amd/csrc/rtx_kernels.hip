@@ -555,470 +555,59 @@ constexpr int kWaveListCap = 128;  // REFINE: candidates a wave keeps for its ow
 // REFINE (dense scenes, long candidate lists): before a wave scans the workgroup's list for its 64 pixels it
 // tests the list, one entry per lane, against the pyramid of just those pixels -- same conservative test and
 // margin as for the macro tile -- and scans the survivors only.
-template <int MODE, bool CULL, int OUT, bool REFINE>
 #ifndef RTX_WAVES_PER_EU
 #define RTX_WAVES_PER_EU 7 // 72 VGPRs: 7 workgroups per CU instead of 6 (20.4 -> 19.6 us per frame; 8 needs spills and gains nothing)
 #endif
+// Where a workgroup stands: in a plain launch the grid is the frame's tile grid; in a batched one (rtx_trace_batch) it is 1-D,
+// workgroup b on tile position b / n of frame b % n.  Computed where they are used (at the head and at the very end of the
+// kernel), from the block index, rather than carried in scalar registers across the pass loop.
+template <bool BATCH>
+struct Where {
+    static __device__ __forceinline__ uint32_t pos(const KArgs& a) { return BATCH ? blockIdx.x / a.batch_n : blockIdx.y * gridDim.x + blockIdx.x; }
+    static __device__ __forceinline__ uint32_t grid_x(const KArgs& a) { return BATCH ? a.batch_gx : gridDim.x; }
+    static __device__ __forceinline__ uint32_t n_tiles(const KArgs& a) { return BATCH ? a.batch_gx * a.batch_gy : gridDim.x * gridDim.y; }
+    static __device__ __forceinline__ bool first_block() { return BATCH ? blockIdx.x == 0u : (blockIdx.x == 0u && blockIdx.y == 0u); }
+    // one frame of a batch leaves the work estimates (the tiles' costs differ little from frame to frame of a round)
+    static __device__ __forceinline__ bool leaves_cost(const KArgs& a) { return BATCH ? blockIdx.x % a.batch_n == 0u : true; }
+};
+
+// The body of the trace kernels lives in rtx_trace_body.inc, included into the two entry points below.
+template <int MODE, bool CULL, int OUT, bool REFINE>
 __global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace(const KArgs a)
 {
-    // REFINE (dense scenes, short per-cell lists, at most 4 sub-tiles): a shorter list and smaller tables, so that its
-    // extra arrays still leave room for 7 workgroups per CU (under 23 405 bytes each)
-    constexpr int kListCap = CULL ? (REFINE ? kListCapRefine : kListCapCull) : kListCapBrute;
-    constexpr int kTable = REFINE ? kMaxMacroRefine : kMaxMacro;
-    __shared__ float4 s_rec[kListCap];
-    __shared__ uint32_t s_idx[kListCap];
-    __shared__ float4 s_col[kTable];             // per column: (m0, m4, m8) * vx
-    __shared__ float4 s_row[kTable];             // per row:    (m1, m5, m9) * vy
-    __shared__ float4 s_plane[3 * kPlaneTable];  // per plane: {n, num} {xlo, xhi, zlo, zhi} {od, gidx}
-    __shared__ uint32_t s_digits[256];           // three decimal digits of 0..255, NUL padded
-    __shared__ __attribute__((aligned(4))) uint8_t s_ramp[68]; // the glyph ramp (RayTracing.h:97-115)
-    __shared__ uint32_t s_wcnt[2][8];            // survivors per wave and half of the current step, double-buffered
-    __shared__ float s_frustum[16];              // the macro tile's five plane normals
-    __shared__ float s_margin[REFINE ? kListCap : 1];                       // REFINE: culling margin of every list entry
-    __shared__ float4 s_wfr[REFINE ? kRefineSub * 4 * 4 : 1];               // REFINE: four side-plane normals per (sub-tile, wave)
-    __shared__ uint16_t s_wlist[REFINE ? 4 : 1][REFINE ? kWaveListCap : 1]; // REFINE: a wave's own candidates (list positions)
-    __shared__ uint32_t s_cost[3];               // this tile's work estimate, summed over the waves; waves done; start time
-    __shared__ uint32_t s_nplanes;               // planes of the LDS table this macro tile can see
-    // What only the rare paths of the pass loop need (the overflow fallback: the item list and the pyramid; planes
-    // beyond the table: the plane arrays) is parked here and read back inside those paths, so that it does not
-    // occupy scalar registers -- or spill slots that every pass reloads -- for the whole loop.
-    __shared__ unsigned long long s_rare_ptr[5]; // item list, pl_a, pl_b, pl_od, sorted position -> sphere index (ties)
-    __shared__ uint32_t s_rare_count;            // items
+    constexpr bool BATCH = false;
+#include "rtx_trace_body.inc"
+}
 
-    const uint32_t tid = threadIdx.x;
-    // The kernel arguments that the head of the workgroup walks through (which tile, which cell, its list, the geometry), requested
-    // in one batch: left to itself the compiler fetches each where it is first used, a scalar round trip at every step of the
-    // dependent chain tile -> cell -> list entries -> geometry.  (The statement costs the dispatch-order and count lookups their
-    // scalar form -- a volatile asm counts as a possible store -- and three SGPR spills; a non-volatile form that ties the values
-    // together instead spilt vector registers, and the dispatch-order lookup as an explicit s_load changed nothing measurable.
-    // Measured as it stands: config 2 24.9 -> 24.5 us alone, config 5 45.7 -> 44.7.)
-    if (CULL) {
-        asm volatile("" ::"s"(a.tile_order), "s"(a.cell_list), "s"(a.cell_count), "s"(a.cell_cap), "s"(a.cells_x), "s"(a.cell_log2gx), "s"(a.cell_log2gy),
-                     "s"(a.sph_geom), "s"(a.ns), "s"(a.tile_log2w), "s"(a.sub_log2nx), "s"(a.nsub), "s"(a.row0));
-    }
-    const uint32_t lw = a.tile_log2w;
-    const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
-    const uint32_t lnx = a.sub_log2nx;           // sub-tiles are laid out nx wide, nsub/nx high
-    const uint32_t nsub = a.nsub;
-    const uint32_t nx = 1u << lnx, ny = nsub >> lnx;
-    const uint32_t mw = tw * nx, mh = th * ny;   // macro tile, pixels
-    // which macro tile: this workgroup's own position in the grid, or what the heaviest-first order assigns to it
-    uint32_t bx = blockIdx.x, by = blockIdx.y;
-    if (a.tile_order != nullptr) {
-        const uint32_t packed = a.tile_order[blockIdx.y * gridDim.x + blockIdx.x];
-        bx = packed & 0xffffu;
-        by = packed >> 16;
-    }
-    const uint32_t mcol0 = bx * mw;
-    const uint32_t mrow0 = a.row0 + by * mh;
-
-    Camera cam;
+// The same rows of a.batch_n frames in one launch (KBatch, rtx_kernels.h): a 1-D grid of batch_n x tiles workgroups, workgroup b
+// on tile position b / batch_n of frame b % batch_n.  The frame's camera, edge basis and output buffer replace the launch's.
+template <int MODE, int OUT>
+__global__ __launch_bounds__(kThreads, RTX_WAVES_PER_EU) void rtx_trace_batch(const KArgs a0, const KBatch kb)
+{
+    const uint32_t frame = blockIdx.x % a0.batch_n;
+    KArgs a = a0;
+    const KFrame& f = kb.f[frame];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        cam.m[i] = a.m[i];
+        a.m[i] = f.m[i];
     }
-    cam.ox = a.ox; cam.oy = a.oy; cam.oz = a.oz;
-    cam.e1 = a.e1; cam.e2 = a.e2; cam.far = a.far;
-    cam.fW = a.fW; cam.fH = a.fH;
-
-    STAMP(0);
-    RTX_X_WG_BEGIN();
-    // what this workgroup stages: the whole scene, or its coarse cell's list (two-level culling)
-    Items items = scene_items(a);
-    uint32_t k0 = 0u, k1 = 0u;
-    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-    bool first_step_requested = false;
-    if (CULL && a.cell_list != nullptr) {
-        const uint32_t cell = (by >> a.cell_log2gy) * a.cells_x + (bx >> a.cell_log2gx);
-        // The head of a workgroup is a chain of dependent loads: dispatch order -> the cell's count -> list entries -> their
-        // geometry.  The first list entries do not need the count: they are requested beside it (a slot past the end of the
-        // list holds whatever the buffer held; clamped to a valid position and ignored by the staging step, like every item
-        // past the count), which takes one round trip to memory out of the chain.
-        const uint32_t* lst = a.cell_list + (size_t)cell * a.cell_cap;
-        const uint32_t cap1 = a.cell_cap - 1u;
-        // The sparse plan's lists rarely reach 256 entries (config 2: 60 .. 250), so there only the first half of the step is
-        // requested ahead (slots past the end are cold lines every frame: 512 slots per workgroup cost config 2 2.1 MB of
-        // reads per frame against 0.8 MB for the whole scene); the dense plan's lists (config 5: ~250 on average) take both.
-        const uint32_t e0 = lst[tid < cap1 ? tid : cap1];
-        uint32_t e1 = 0u;
-        if (REFINE) e1 = lst[(uint32_t)kThreads + tid < cap1 ? (uint32_t)kThreads + tid : cap1];
-        const uint32_t listed = a.cell_count[cell];
-        // (their geometry too, unconditionally: behind a test of the count the compiler would sink the whole step behind the wait
-        // for the count)
-        const uint32_t last = a.ns - 1u;
-        k0 = e0 < a.ns ? e0 : last;
-        g0 = items.geom[k0];
-        if (REFINE) {
-            k1 = e1 < a.ns ? e1 : last;
-            g1 = items.geom[k1];
-        }
-        if (listed <= a.cell_cap) { // else: the list did not fit; the whole scene is always a superset
-            items.list = lst;
-            items.count = listed;
-            first_step_requested = listed != 0u && !ABL(1u);
-            if (!REFINE && first_step_requested && listed > (uint32_t)kThreads) {
-                // (rare in the sparse plan; the count has long arrived by now -- it was requested beside the first entries, one
-                // round trip against their two -- so the common case pays nothing for this test)
-                g1 = load_item(items, (uint32_t)kThreads + tid, k1);
-            }
-        }
-    }
-    if (ABL(1u)) items.count = 0u;
-    const uint32_t ns = items.count;
-    if (tid == 0u) {
-        s_rare_ptr[0] = (unsigned long long)(uintptr_t)items.list;
-        s_rare_ptr[1] = (unsigned long long)(uintptr_t)a.pl_a;
-        s_rare_ptr[2] = (unsigned long long)(uintptr_t)a.pl_b;
-        s_rare_ptr[3] = (unsigned long long)(uintptr_t)a.pl_od;
-        s_rare_ptr[kRareSortedIdx] = (unsigned long long)(uintptr_t)a.sph_sorted_idx;
-        s_rare_count = items.count;
-    }
-    // first staging step's loads go out before anything else
-    if (!first_step_requested) {
-        g0 = load_item(items, tid, k0);
-        g1 = load_item(items, kThreads + tid, k1);
-    }
-
-    // ---- per-workgroup tables (visible after the first barrier below)
-    s_digits[tid] = digits_word(tid);
-    // the glyph ramp is requested now and written to LDS after the staging loop (first read: encode), so that no
-    // wave waits for it here
-    uint32_t ramp4 = 0u;
-    if (tid < 17u) {
-        ramp4 = reinterpret_cast<const uint32_t*>(kRamp)[tid];
-    }
-    if (tid == 0u) {
-        s_cost[0] = 0u;
-        s_cost[1] = 0u;
-        if (a.tile_cost != nullptr) {
-            s_cost[2] = (uint32_t)__builtin_amdgcn_s_memrealtime(); // 100 MHz, one clock per XCD: when this workgroup started
-        }
-    }
-    if (tid < mw) {
-        // convertedX = (2 * column - (float)x) / x;  vx = convertedX * element1   (RayTracing.cu:17,20)
-        const uint32_t c = mcol0 + tid < a.W ? mcol0 + tid : a.W - 1u;
-        const float vx = (((float)(2u * c) - cam.fW) / cam.fW) * cam.e1;
-        s_col[tid] = make_float4(cam.m[0] * vx, cam.m[4] * vx, cam.m[8] * vx, 0.0f);
-    } else if (tid - mw < mh) {
-        // convertedY = ((float)y - row * 2) / y;  vy = convertedY * element2   (RayTracing.cu:16,20)
-        const uint32_t rr = mrow0 + (tid - mw);
-        const uint32_t r = rr < a.row_end ? rr : a.row_end - 1u;
-        const float vy = ((cam.fH - (float)(r * 2u)) / cam.fH) * cam.e2;
-        s_row[tid - mw] = make_float4(cam.m[1] * vy, cam.m[5] * vy, cam.m[9] * vy, 0.0f);
-    }
-    const uint32_t np = ABL(8u) ? 0u : a.np;
-    const uint32_t np_tab = np < (uint32_t)kPlaneTable ? np : (uint32_t)kPlaneTable;
-    // plane records are requested here and written to the LDS table after the staging loop, so that
-    // their latency overlaps with it
-    float4 pla = make_float4(0.f, 0.f, 0.f, 0.f), plb = pla, pld = pla;
-    if (tid < np_tab) {
-        pla = a.pl_a[tid];
-        plb = a.pl_b[tid];
-        pld = a.pl_od[tid];
-    }
-
-    // The culling pyramid is the same for the whole workgroup: wave 0 computes it, the others pick it
-    // up from LDS into scalar registers.
-    TileFrustum fr;
-    if (CULL) {
-        const uint32_t plane_lanes = REFINE ? 5u + nsub * 16u : 5u;
-        if (tid < ((plane_lanes + 63u) & ~63u)) { // wave 0, and wave 1 as well when REFINE needs more than 64 lanes
-            // lanes 0..3 each build one side plane, lane 4 picks up the camera plane (the other lanes idle along) ...
-            uint32_t pc0 = mcol0, pr0 = mrow0, pw = mw, ph = mh, pk = tid;
-            if (REFINE && tid >= 5u) {
-                // ... unless REFINE gives them the pyramids of the 64-pixel pieces: lane 5 + 4*region + k builds side
-                // plane k of region = sub-tile * 4 + wave (a wave's pixels: all tw columns, 64/tw rows; the camera plane
-                // is the macro tile's already)
-                const uint32_t q = tid - 5u, region = q >> 2, sub = region >> 2, w = region & 3u;
-                pk = q & 3u;
-                pc0 = mcol0 + (sub & (nx - 1u)) * tw;
-                pr0 = mrow0 + (sub >> lnx) * th + w * (64u >> lw);
-                pw = tw;
-                ph = 64u >> lw;
-            }
-            const V3 n = tile_plane(a, cam, pc0, pr0, pw, ph, pk);
-            if (tid < 5u) {
-                s_frustum[3 * tid + 0] = n.x;
-                s_frustum[3 * tid + 1] = n.y;
-                s_frustum[3 * tid + 2] = n.z;
-            } else if (REFINE && tid - 5u < nsub * 16u) {
-                s_wfr[tid - 5u] = make_float4(n.x, n.y, n.z, 0.0f);
-            }
-        }
-        lds_barrier();
+    a.ox = f.ox;
+    a.oy = f.oy;
+    a.oz = f.oz;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            fr.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
-            fr.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 1])));
-            fr.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
-        }
+    for (int i = 0; i < 3; i++) {
+        a.edge_up_p[i] = f.edge_up_p[i];
+        a.edge_up_q[i] = f.edge_up_q[i];
+        a.edge_right_p[i] = f.edge_right_p[i];
+        a.edge_right_q[i] = f.edge_right_q[i];
+        a.edge_fwd[i] = f.edge_fwd[i];
     }
-
-    STAMP(1);
-    // ---- stage the whole scene once
-    uint32_t total = 0; // candidates in the list; identical in every thread
-    uint32_t parity = 0;
-    bool overflow = !CULL && ns > (uint32_t)kListCap; // brute: every sphere is a candidate
-    for (uint32_t base = 0; base < ns && !overflow; base += kChunk, parity ^= 1u) {
-        const float4 c0 = g0, c1 = g1;
-        const uint32_t j0 = k0, j1 = k1;
-        g0 = load_item(items, base + kChunk + tid, k0); // prefetch the next step
-        g1 = load_item(items, base + kChunk + kThreads + tid, k1);
-        if (total > (uint32_t)(kListCap - kChunk)) {
-            overflow = true; // the list cannot take another step: fall back to one scene walk per sub-tile
-            break;
-        }
-        total = stage_chunk<CULL>(cam, fr, ns, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, parity, total, ABL(2u), REFINE ? s_margin : nullptr);
-    }
-    if (tid < 17u) {
-        reinterpret_cast<uint32_t*>(s_ramp)[tid] = ramp4;
-    }
-    if (tid < 64u) {
-        // ray-independent parts of Plane::Trace (Plane.cu:52, 60-67): Dot(planePos - origin, n) and the bounds.  Only
-        // the planes that some pixel ray of this macro tile can hit enter the table (plane_invisible), in table order.
-        const V3 p = v3(pla.x, pla.y, pla.z), n = v3(plb.x, plb.y, plb.z);
-        const float num = dot(sub(p, v3(cam.ox, cam.oy, cam.oz)), n);
-        const float hw = pla.w * 0.5f, hh = plb.w * 0.5f;
-        const float4 bounds = make_float4(p.x - hw, p.x + hw, p.z - hh, p.z + hh);
-        // (from two planes on: with a single plane the test costs the workgroup what leaving the plane out saves --
-        // measured at C2, 19.9 vs 20.2 us per frame)
-        const bool listed = tid < np_tab && !(CULL && np >= 2u && !ABL(128u) && plane_invisible(cam, mcol0, mrow0, mw, mh, n, num, bounds));
-        const unsigned long long m = __ballot(listed);
-        if (listed) {
-            const uint32_t at = (uint32_t)__popcll(m & ((1ull << tid) - 1ull));
-            s_plane[3 * at + 0] = make_float4(n.x, n.y, n.z, num);
-            s_plane[3 * at + 1] = bounds;
-            s_plane[3 * at + 2] = pld;
-        }
-        if (tid == 0u) {
-            s_nplanes = (uint32_t)__popcll(m);
-        }
-    }
-    // view-density feedback for the host: workgroups with a long candidate list report its length (a handful per launch in
-    // an ordinary view, none at all in most)
-    if (CULL && a.longest_list != nullptr && tid == 0u) {
-        const uint32_t len = overflow ? (uint32_t)kListCap : total;
-        if (len >= a.longest_from) atomicMax(a.longest_list + a.longest_slot, len);
-        if (blockIdx.x == 0u && blockIdx.y == 0u) a.longest_list[a.longest_slot == 2u ? 0u : a.longest_slot + 1u] = 0u;
-    }
-    lds_barrier(); // list complete, tables visible
-    const uint32_t np_vis = (uint32_t)__builtin_amdgcn_readfirstlane(s_nplanes); // planes in the table
-    STAMP(2);
-
-    // ---- one pass per sub-tile.  (Drawing the waves' 64-pixel shares of the sub-tiles from a counter in LDS, so that a
-    // wave whose pixels miss everything moves on while its neighbour shades, was measured and dropped: +6 % per frame --
-    // profiles/r02_c_single_launch_experiments.md.)
-    uint32_t wcost = 0; // this wave's work estimate for the heaviest-first order (wave-uniform)
-    RTX_X_WAVE_FEATURES();
-    const uint32_t tx = tid & (tw - 1u), ty = tid >> lw;
-#pragma unroll 1
-    for (uint32_t j = 0; j < nsub; j++) {
-        const uint32_t jx = j & (nx - 1u), jy = j >> lnx;
-        const uint32_t scol0 = mcol0 + jx * tw, srow0 = mrow0 + jy * th;
-        if (scol0 >= a.W || srow0 >= a.row_end) {
-            continue; // sub-tile entirely outside the frame (uniform)
-        }
-        const uint32_t col = scol0 + tx, row = srow0 + ty;
-        const bool in_frame = col < a.W && row < a.row_end;
-        const bool newline_col = col + 1u == a.W;
-        // lanes outside the frame trace a clamped pixel (the tables clamp) so every lane runs the same loops
-        Ray ray = ray_from_tables(cam, s_col[jx * tw + tx], s_row[jy * th + ty]);
-        if (REFINE) ray.divTwoA = rcp_cr(2.0f * ray.a); // RayTracing.cu:93, once per ray here (see test_candidate)
-        Best b;
-        b.t = kNoHit;
-        b.k = 0xffffffffu;
-        uint32_t scanned = total; // candidates this wave tests in this pass (the overflow path: at least that many)
-        uint32_t slow = 0;        // ... and how many of them reach the exact test
-        if (!overflow) {
-            bool refined = false;
-            if (REFINE && total > 8u) {
-                // this wave's pyramid (uniform reads), then the list, one entry per lane
-                const uint32_t wave = tid >> 6, lane = tid & 63u;
-                V3 wn[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float4 pn = s_wfr[(j * 4u + wave) * 4u + (uint32_t)k];
-                    wn[k] = v3(pn.x, pn.y, pn.z);
-                }
-                uint32_t cnt = 0;
-                for (uint32_t base = 0; base < total && cnt <= (uint32_t)kWaveListCap; base += 64u) {
-                    const uint32_t i = base + lane;
-                    const uint32_t ii = i < total ? i : total - 1u;
-                    const float4 sr = s_rec[ii];
-                    const float mg = s_margin[ii];
-                    bool out = false;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        out = out || (wn[k].x * sr.x + wn[k].y * sr.y + wn[k].z * sr.z > mg); // as tile_culls (every list entry has passed the camera plane)
-                    }
-                    const bool keepw = i < total && !out;
-                    const unsigned long long m = __ballot(keepw);
-                    const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (keepw && pos < (uint32_t)kWaveListCap) {
-                        s_wlist[wave][pos] = (uint16_t)i;
-                    }
-                    cnt += (uint32_t)__popcll(m);
-                }
-                cnt = __builtin_amdgcn_readfirstlane(cnt);
-                if (cnt <= (uint32_t)kWaveListCap) {
-                    refined = true;
-                    scanned = cnt + (total >> 4); // its own candidates, and the refinement's share
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the wave's own LDS writes, before it reads them back
-                    for (uint32_t q = 0; q < cnt; q++) {
-                        const uint32_t i = s_wlist[wave][q];
-                        test_candidate<REFINE>(ray, s_rec[i], s_idx, s_rare_ptr, i, b, slow);
-                    }
-                }
-            }
-            if (!refined) {
-                if (!ABL(4u)) scan_candidates<REFINE>(ray, s_rec, s_idx, s_rare_ptr, total, b, slow);
-            }
-        } else {
-            // rare: more candidates than the list holds.  Walk the scene again for this sub-tile, folding
-            // the list into the best hit whenever it fills.
-            lds_barrier();
-            // the item list and the pyramid, back from LDS (the compiler barrier keeps the reads in this branch instead
-            // of hoisting them out of the pass loop)
-            asm volatile("" ::: "memory");
-            Items its = scene_items(a);
-            its.list = reinterpret_cast<const uint32_t*>((uintptr_t)s_rare_ptr[0]);
-            its.count = s_rare_count;
-            const uint32_t nit = its.count;
-            TileFrustum fr2;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                fr2.n[k].x = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 0])));
-                fr2.n[k].y = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 1])));
-                fr2.n[k].z = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(s_frustum[3 * k + 2])));
-            }
-            uint32_t tot = 0, par = 0;
-            uint32_t i0, i1;
-            float4 h0 = load_item(its, tid, i0), h1 = load_item(its, kThreads + tid, i1);
-            for (uint32_t base = 0; base < nit; base += kChunk, par ^= 1u) {
-                const float4 c0 = h0, c1 = h1;
-                const uint32_t j0 = i0, j1 = i1;
-                h0 = load_item(its, base + kChunk + tid, i0);
-                h1 = load_item(its, base + kChunk + kThreads + tid, i1);
-                tot = stage_chunk<CULL>(cam, fr2, nit, base, c0, c1, j0, j1, s_rec, s_idx, s_wcnt, par, tot, false);
-                if (tot > (uint32_t)(kListCap - kChunk) || base + kChunk >= nit) {
-                    lds_barrier();
-                    scan_candidates<REFINE>(ray, s_rec, s_idx, s_rare_ptr, tot, b, slow);
-                    tot = 0;
-                }
-            }
-        }
-
-        // ---- winner among spheres: its records are requested now and first used after the plane tests
-        // (the creation index only in an exact tie with a plane)
-        uint32_t best_gidx = 0xffffffffu;
-        float4 wgeom = make_float4(0.f, 0.f, 0.f, 0.f), wod = wgeom;
-        if (b.k != 0xffffffffu) { // (by position: the arrays staging read, whose lines are in this XCD's L2 already)
-            wgeom = a.sph_geom[b.k];
-            wod = a.sph_od[b.k];
-        }
-        const bool sphere_hit_any = b.k != 0xffffffffu;
-
-        // ---- planes: hoisted form from LDS (wave-uniform index: broadcast reads), Plane.cu:38-72
-        uint32_t plane_q = 0xffffffffu; // winning plane, if a plane beats the best sphere
-        for (uint32_t q = 0; q < np_vis; q++) {
-            const float4 pn = s_plane[3 * q + 0];
-            const float dn = ray.d.x * pn.x + ray.d.y * pn.y + ray.d.z * pn.z;
-            if (dn > 0.0f || fabsf(dn - 0.0f) < 1.1920928955078125e-7f) {
-                continue;
-            }
-            const float t1 = pn.w / dn;
-            if (t1 <= 0.0f) {
-                continue;
-            }
-            const float4 bd = s_plane[3 * q + 1];
-            const float hx = ray.o.x + ray.d.x * t1, hz = ray.o.z + ray.d.z * t1;
-            if ((hx <= bd.x || hx >= bd.y) || (hz <= bd.z || hz >= bd.w)) {
-                continue;
-            }
-            const uint32_t gi = __float_as_uint(s_plane[3 * q + 2].w);
-            if (t1 < b.t || (t1 == b.t && gi < (plane_q != 0xffffffffu ? best_gidx : (sphere_hit_any ? __float_as_uint(wod.w) : 0xffffffffu)))) {
-                b.t = t1;
-                best_gidx = gi;
-                plane_q = q;
-            }
-        }
-        if (np > np_tab) { // beyond the LDS table (more than 16 planes): the direct form, array pointers back from LDS
-            asm volatile("" ::: "memory");
-            const float4* rare_pl_a = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[1]);
-            const float4* rare_pl_b = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[2]);
-            const float4* rare_pl_od = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[3]);
-          for (uint32_t q = np_tab; q < np; q++) {
-            const float4 pa = rare_pl_a[q]; // px py pz width
-            const float4 pb = rare_pl_b[q]; // nx ny nz height
-            float t;
-            if (plane_hit(ray, v3(pa.x, pa.y, pa.z), v3(pb.x, pb.y, pb.z), pa.w, pb.w, t)) {
-                const uint32_t gi = __float_as_uint(rare_pl_od[q].w);
-                if (t < b.t || (t == b.t && gi < (plane_q != 0xffffffffu ? best_gidx : (sphere_hit_any ? __float_as_uint(wod.w) : 0xffffffffu)))) {
-                    b.t = t;
-                    best_gidx = gi;
-                    plane_q = q;
-                }
-            }
-        }
-        }
-
-        // ---- shade the winner (RayTracing.cu:123-157).  Values of a missed pixel are never encoded.
-        float distance = kNoHit, shadingValue = 0.0f;
-        V3 normal = ray.d, colour = ray.d;
-        if (ABL(32u)) {
-            distance = b.t; shadingValue = ray.d.x;
-        } else if (plane_q != 0xffffffffu || b.k != 0xffffffffu) {
-            V3 n0, od;
-            if (plane_q != 0xffffffffu) {
-                // the plane's normal and colour: from the LDS table when it is there (the same values)
-                float4 pb, pd;
-                if (plane_q < np_tab) {
-                    pb = s_plane[3u * plane_q + 0u];
-                    pd = s_plane[3u * plane_q + 2u];
-                } else {
-                    asm volatile("" ::: "memory");
-                    pb = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[2])[plane_q];
-                    pd = reinterpret_cast<const float4*>((uintptr_t)s_rare_ptr[3])[plane_q];
-                }
-                n0 = v3(pb.x, pb.y, pb.z);
-                od = v3(pd.x, pd.y, pd.z);
-            } else {
-                // Sphere.cu:67: (origin + direction * t1 - spherePos).Normalize_GPU()
-                n0 = normalize_gpu(sub(add(ray.o, mulf(ray.d, b.t)), v3(wgeom.x, wgeom.y, wgeom.z)));
-                od = v3(wod.x, wod.y, wod.z);
-            }
-            distance = b.t;
-            normal = normalize_gpu(n0);                                         // RayTracing.cu:129
-            shadingValue = normal.x * 1.0f + normal.y * 0.0f + normal.z * 0.0f; // Dot(normal, (1,0,0)), :133
-            if (MODE != RTX_K_RGB_NORMALS && MODE != RTX_K_SDL) {
-                colour = ABL(16u) ? mulf(od, 255.0f) : shade(ray, distance, normal, od);
-            }
-        }
-
-        if (MODE != RTX_K_SDL && !ABL(64u)) {
-            encode_and_store<MODE, OUT>(a, cam, s_digits, s_ramp, in_frame, newline_col, row, col, distance, normal, colour, shadingValue);
-        }
-        // per wave and pass: ray generation, planes and encoding; the exact test per candidate; winner normal, shading
-        // and the hit tests' slow path when the wave sees anything (instruction counts of tools/ablate_pmc_gpu.sh)
-        wcost += kCostPass + kCostCandidate * scanned + (__ballot(in_frame && distance <= cam.far) != 0ull ? kCostShaded : 0u);
-        STAMP(3 + (j < 9u ? j : 9u));
-        RTX_X_PASS_END(slow, __ballot(in_frame && distance <= cam.far) != 0ull, scanned, total, wcost);
-    }
-    RTX_X_KERNEL_END(wcost);
-    // ---- leave this tile's work estimate for rtx_order_tiles: the sum over the four waves, stored by the last one
-    // to get here (LDS atomics of one wave execute in order, so the fourth increment sees all four sums)
-    // (lane number from mbcnt: keeping tid & 63 alive across the whole kernel for this one test costs a register)
-    if (a.tile_cost != nullptr && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
-        atomicAdd(&s_cost[0], (uint32_t)__builtin_amdgcn_readfirstlane(wcost));
-        if (atomicAdd(&s_cost[1], 1u) == (uint32_t)(kThreads / 64 - 1)) {
-            // the estimate by tile; when the workgroup started and ended by dispatch position (rtx_balance_tiles sets
-            // the two against each other: the workgroups that shared a CU, and how long that CU took)
-            const uint32_t n_tiles = gridDim.x * gridDim.y, pos = blockIdx.y * gridDim.x + blockIdx.x;
-            a.tile_cost[by * gridDim.x + bx] = *reinterpret_cast<volatile uint32_t*>(&s_cost[0]);
-            a.tile_cost[n_tiles + pos] = *reinterpret_cast<volatile uint32_t*>(&s_cost[2]);
-            a.tile_cost[2u * n_tiles + pos] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        }
-    }
+    a.edge_pp = f.edge_pp;
+    a.edge_qrqr = f.edge_qrqr;
+    a.edge_qcqc = f.edge_qcqc;
+    a.out = f.out;
+    constexpr bool BATCH = true, CULL = true, REFINE = false;
+#include "rtx_trace_body.inc"
 }
 
 // Level 1 of the two-level culling used for large scenes: the scene is binned into coarse cells (blocks of
@@ -1728,6 +1317,50 @@ extern "C" const char* rtx_k_launch_trace(const KArgs* a, int mode, int cull, vo
 #undef RTX_LAUNCH_MODE
 #undef RTX_LAUNCH_OUT
 #undef RTX_LAUNCH
+    *hip_error = (int)hipGetLastError();
+    return name;
+}
+
+extern "C" const char* rtx_k_launch_trace_batch(const KArgs* a, const KBatch* kb, int mode, void* stream_v, int* hip_error)
+{
+    using namespace rtx;
+    hipStream_t stream = (hipStream_t)stream_v;
+    const uint32_t lw = a->tile_log2w;
+    const uint32_t tw = 1u << lw, th = (uint32_t)kThreads >> lw;
+    const uint32_t nx = 1u << a->sub_log2nx, ny = a->nsub >> a->sub_log2nx;
+    const uint32_t mw = tw * nx, mh = th * ny;
+    *hip_error = 0;
+    if (a->nsub == 0 || nx * ny != a->nsub || mw > (uint32_t)kMaxMacro || mh > (uint32_t)kMaxMacro || mw + mh > (uint32_t)kThreads || a->refine ||
+        a->batch_n == 0 || a->batch_n > (uint32_t)kMaxBatch || a->compact > 1u) {
+        return nullptr;
+    }
+    const uint32_t rows = a->row_end - a->row0;
+    const uint64_t gx = (a->W + mw - 1u) / mw, gy = (rows + mh - 1u) / mh, blocks = gx * gy * a->batch_n;
+    if (gx != a->batch_gx || gy != a->batch_gy || blocks == 0 || blocks >= (1ull << 31)) {
+        return nullptr;
+    }
+    const dim3 grid((uint32_t)blocks, 1, 1), block(kThreads, 1, 1);
+    const char* name = nullptr;
+    const unsigned lds_pad = rtx_x_lds_pad(); // 0 in the product build
+#define RTX_LAUNCH_BATCH(M)                                                                               \
+    do {                                                                                                  \
+        if (a->compact == 0u) {                                                                           \
+            hipLaunchKernelGGL((rtx_trace_batch<M, kOutRecords>), grid, block, lds_pad, stream, *a, *kb); \
+            name = "rtx_trace_batch<" #M ">";                                                             \
+        } else {                                                                                          \
+            hipLaunchKernelGGL((rtx_trace_batch<M, kOutCompact>), grid, block, lds_pad, stream, *a, *kb); \
+            name = "rtx_trace_batch<" #M ",compact>";                                                     \
+        }                                                                                                 \
+    } while (0)
+    switch (mode) {
+    case RTX_K_BIT_ASCII: RTX_LAUNCH_BATCH(RTX_K_BIT_ASCII); break;
+    case RTX_K_BIT_PIXEL: RTX_LAUNCH_BATCH(RTX_K_BIT_PIXEL); break;
+    case RTX_K_RGB_ASCII: RTX_LAUNCH_BATCH(RTX_K_RGB_ASCII); break;
+    case RTX_K_RGB_PIXEL: RTX_LAUNCH_BATCH(RTX_K_RGB_PIXEL); break;
+    case RTX_K_RGB_NORMALS: RTX_LAUNCH_BATCH(RTX_K_RGB_NORMALS); break;
+    default: return nullptr;
+    }
+#undef RTX_LAUNCH_BATCH
     *hip_error = (int)hipGetLastError();
     return name;
 }

@@ -195,7 +195,7 @@ def parse_args(argv=None):
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="N=1: frames rendered concurrently on separate HIP streams into separate frame buffers (default 4; 6 from 16384 spheres; "
                          "1 = strictly one launch after the other, the form the rocprof summaries are taken in).  "
-                         "N>1: render streams the slab launches of a round are spread over (default 2 for N<=2, else 4)")
+                         "N>1: render streams the slab launches of a round are spread over (default 1: the loop's own stream, one batched launch per round)")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed, uncounted run-in before the warm-up steps so that the GPU is at its running clocks "
                          "(N>1: the equivalent number of frames, fixed so that all ranks agree)")
@@ -811,7 +811,11 @@ def run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, config,
     apply_options(R, ctx, args)
     ctx.render_rows(params, mode, 0, 1)   # uploads the scene (a HIP graph capture later on must not have to)
     ctx.synchronize()
-    F = args.frames_in_flight if args.frames_in_flight > 0 else (4 if world > 2 else 2)
+    # render streams of a rank's slab launches.  Default 1: every slab of a round on the loop's own stream, where the library
+    # traces them with ONE batched launch per <= 16 frames (RTX_OPT_BATCH, rtx_trace_batch: eight 135-row slab-frames of 1080p in
+    # 26 us against 88-113 us as eight launches over 2-4 streams, tools/batch_slabs_gpu.py) and no fork / join is needed; F > 1
+    # spreads the slabs over F streams of their own, a launch each, as rounds 1-3 did.
+    F = args.frames_in_flight if args.frames_in_flight > 0 else 1
     bounds = sharding.row_bounds(H, world)
     row0, rows = bounds[rank], bounds[rank + 1] - bounds[rank]
     # The loop runs on a stream of its own, made torch's current stream: the collectives are ordered after it, and
@@ -906,7 +910,7 @@ def run_sharded(args, torch, dist, R, sharding, rank, world, local_rank, config,
 
         pipe = sharding.RowShardedRounds(dist, torch, rank, world, W, H, S, "cuda", nbuf=2, frames_per_root=M,
                                          pixel_bytes=4 if compact else None, finish=finish if compact else None, roots=roots)
-        rstreams = [torch.cuda.Stream() for _ in range(F)]
+        rstreams = [torch.cuda.Stream() for _ in range(F)] if F > 1 else [stream]
         torch.cuda.synchronize()
         RF = pipe.round_frames
         submitters = [ctx.make_slab_submitter(params, mode, row0, rows, row0,

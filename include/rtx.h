@@ -122,6 +122,11 @@ enum rtx_option {
                                * frames' cameras and output buffers travel in the kernel arguments), instead of a launch each -- a rank's slab of
                                * a sharded 1080p frame is 255 workgroups, far too few to fill 256 CUs.  Taken where the plan has neither
                                * two-level culling nor per-wave refinement and the frames differ in camera only.  -1 auto (on), 0 off, 1 on */
+    RTX_OPT_UPDATE_WORDS = 15, /* rtx_update / rtx_update_begin trace 4-byte pixel words (RTX_RENDER_COMPACT) and minimise from them instead of
+                               * writing the 12 / 20-byte records and reading them back twice: the same minimised stream with a fifth of the
+                               * memory traffic (1080p RGB: 8.3 MB written + 16.6 MB read instead of 41.5 + 83).  The context's frame buffer
+                               * is then not written by an Update (it keeps what the last rtx_render left).  -1 auto (on), 0 off (records:
+                               * the frame buffer holds the frame after every Update, as the reference's m_deviceResultArray does), 1 on */
     RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */
     RTX_OPT_GROUP_WIRE = 13,  /* device groups: enum rtx_group_wire -- what travels: compact pixel words (default) or records */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
@@ -317,6 +322,11 @@ int rtx_read_frame(rtx_ctx* ctx, void* host_out, size_t bytes);
  * own minimise buffer).  *out_bytes receives the minimised length.  Blocking. */
 int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, void* d_out, size_t* out_bytes);
 void* rtx_minimized_device_ptr(rtx_ctx* ctx);
+/* The same pass over W*H compact pixel words (RTX_RENDER_COMPACT: what a sharded frame's slabs travel as) instead of records:
+ * the stream is byte for byte what rtx_minimize makes of the records rtx_expand would write from these words.  A word
+ * 0xffffffff outside column W-1 is an empty slot (a slot whose record would be all NUL).  d_words: device memory, 4-byte
+ * aligned; d_out as for rtx_minimize.  Blocking.  Not with RTX_SDL. */
+int rtx_minimize_words(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_words, void* d_out, size_t* out_bytes);
 
 /* ---- UpdateObjects: the physics kernel Update launches before tracing (RayTracingManager.cu:10-44,
  * 89-107; Sphere.cu:15-23), with a launch shape that stays valid past 1024 objects. */
@@ -325,7 +335,8 @@ int rtx_update_objects(rtx_ctx* ctx, double dt);
 /* ---- RayTracingManager::Update (RayTracingManager.cu:76-154) in one call: params upload, zero
  * semantics, UpdateObjects(dt) when run_physics != 0, trace, GPU minimise, and the copy of the
  * minimised stream to host_out (room for 20*W*H bytes).  On return *out_bytes is what the
- * reference hands to PrintMachine::SetDataInBackBuffer (RayTracingManager.cu:150). */
+ * reference hands to PrintMachine::SetDataInBackBuffer (RayTracingManager.cu:150).  (By default the frame is traced as pixel
+ * words and minimised from those, RTX_OPT_UPDATE_WORDS: the stream is the same, the context's frame buffer is left alone.) */
 int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics,
                void* host_out, size_t* out_bytes);
 

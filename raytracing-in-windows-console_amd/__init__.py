@@ -26,7 +26,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_D
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
 OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER, OPT_VIEW_ADAPT, OPT_SORTED_STORE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN, STAT_CELL_CAPACITY_FLOOR, STAT_VIEW_DENSE, STAT_DENSITY_SWITCHES = 101, 102, 103, 104, 105, 106, 107, 108, 109
-OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH = 12, 13, 14
+OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS = 12, 13, 14, 15
 STAT_BATCHED_LAUNCHES = 114
 STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, EXCHANGE_RCCL_ALL = 0, 1, 2, 3
@@ -91,6 +91,7 @@ _SIGNATURES = [
     ("rtx_read_frame", C.c_int, [_P, _P, C.c_size_t]),
     ("rtx_minimize", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P, _P, C.POINTER(C.c_size_t)]),
     ("rtx_minimized_device_ptr", _P, [_P]),
+    ("rtx_minimize_words", C.c_int, [_P, C.c_int, C.c_size_t, C.c_size_t, _P, _P, C.POINTER(C.c_size_t)]),
     ("rtx_update_objects", C.c_int, [_P, C.c_double]),
     ("rtx_update", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_size_t)]),
     ("rtx_update_begin", C.c_int, [_P, C.POINTER(Params), C.c_int, C.c_double, C.c_int, _P, C.POINTER(C.c_int)]),
@@ -450,6 +451,11 @@ class Context:
     def minimize(self, mode, w, h, d_in=None, d_out=None):
         n = C.c_size_t()
         self._check(lib().rtx_minimize(self._h, mode, w, h, d_in, d_out, C.byref(n)))
+        return n.value
+
+    def minimize_words(self, mode, w, h, d_words, d_out=None):
+        n = C.c_size_t()
+        self._check(lib().rtx_minimize_words(self._h, mode, w, h, d_words, d_out, C.byref(n)))
         return n.value
 
     @property

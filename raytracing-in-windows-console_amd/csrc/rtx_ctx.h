@@ -31,6 +31,9 @@ struct rtx_ctx {
     uint8_t* d_min = nullptr;       // minimise output (allocated on first use)
     void* d_scan = nullptr;         // minimise scratch
     size_t scan_bytes = 0;
+    uint32_t* d_words = nullptr;    // rtx_update's pixel words (W * H; allocated on first use)
+    size_t words_cap = 0;
+    int64_t opt_update_words = -1;  // -1 auto (on), 0 off: rtx_update traces pixel words and minimises from them
     uint8_t* d_grey = nullptr;
     size_t dirty_hi = 0;            // bytes of d_frame that may be non-zero
 
@@ -172,7 +175,9 @@ struct rtx_ctx {
     // buffer, scan scratch and events; the copy of slot k's stream to the host runs on copy_stream while slot
     // k^1 is being traced
     struct UpdateSlot {
-        uint8_t* d_frame = nullptr;
+        uint8_t* d_frame = nullptr;  // (the record form only)
+        uint32_t* d_words = nullptr; // (the word form only)
+        size_t words_cap = 0;
         uint8_t* d_min = nullptr;
         void* d_scan = nullptr;
         size_t scan_bytes = 0;

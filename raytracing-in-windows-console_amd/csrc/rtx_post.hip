@@ -4,6 +4,7 @@
 #include "rtx_ctx.h"
 #include "rtx_group.h"
 #include "rtx_device.hpp"
+#include "rtx_records.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -373,6 +374,214 @@ __global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, u
     }
 }
 
+// ---------------------------------------------------------------- Minimize from compact pixel words
+//
+// The same pass over the 4-byte pixel words the trace kernels can store instead of records (RTX_RENDER_COMPACT, rtx.h): a word
+// carries everything its record is made of, so the pass reads 4 bytes per pixel where the record form reads 12 or 20 -- twice.
+// rtx_update traces words and minimises from them: 8.3 MB written and 2 x 8.3 MB read per 1080p frame instead of 41.5 MB and
+// 2 x 41.5 MB (the full-size records never exist), and a device group gathers the words it minimises from (no expansion).
+// Slot rules as above, stated on words:
+//   * column W-1                          -> '\n'
+//   * word 0xffffffff elsewhere           -> an empty slot (all NUL as a record): emits nothing, is not an ESC slot
+//   * any other word (0 = miss)           -> an ESC slot: its record is record_words<MODE>(word); the colour Minimize compares
+//     (bytes 7-9 [, 11-13, 15-17] of the record: the decimal digits) is a function of the word's colour bytes alone -- the
+//     digits of (r, g, b) or of the xterm index; a miss carries the digits of (0, 0, 0) resp. of index 16 (App. B) -- so
+//     "same colour digits" is "same colour key".
+constexpr int kWPerThread = 4;
+constexpr int kWSlotsPerBlock = kThreads * kWPerThread; // 1024 slots = 4 KB of words per block
+constexpr uint32_t kNoWord = 0xffffffffu;               // = kCompactNewline
+
+template <int MODE>
+__device__ __forceinline__ uint32_t colour_key(uint32_t w)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    return kRgb ? (w & 0x00ffffffu) : (w != 0u ? (w & 0xffu) : 16u);
+}
+
+// s_w[0..1] = the two words before the block's first slot (kNoWord where the frame begins), s_w[2 + li] = word of slot base + li
+__device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, uint64_t base, uint64_t n_slots, uint32_t* s_w)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint64_t g0 = base + (uint64_t)tid * kWPerThread;
+    if (g0 + kWPerThread <= n_slots && ((uintptr_t)(words + g0) & 15u) == 0u) {
+        const uint4 v = *reinterpret_cast<const uint4*>(words + g0);
+        s_w[2 + tid * kWPerThread + 0] = v.x;
+        s_w[2 + tid * kWPerThread + 1] = v.y;
+        s_w[2 + tid * kWPerThread + 2] = v.z;
+        s_w[2 + tid * kWPerThread + 3] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kWPerThread; k++) {
+            s_w[2 + tid * kWPerThread + k] = g0 + k < n_slots ? words[g0 + k] : kNoWord;
+        }
+    }
+    if (tid < 2u) {
+        s_w[tid] = base + tid >= 2u ? words[base + tid - 2u] : kNoWord;
+    }
+}
+
+// Emitted length of slot g (column col, staged at s_w[2 + li]); `w` receives its word.
+template <int MODE>
+__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w)
+{
+    constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
+    w = s_w[2 + li];
+    if (col == W - 1u) {
+        return 1u; // newline
+    }
+    if (w == kNoWord) {
+        return 0u; // empty slot
+    }
+    if (g == 0) {
+        return S; // first pixel of the frame
+    }
+    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's last column
+    const int back = col == 0u ? 2 : 1;
+    if (g >= (uint64_t)back) {
+        const uint32_t pw = s_w[2 + li - back];
+        if (pw != kNoWord) {
+            return colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
+        }
+    }
+    // not a fully rendered frame (empty slots in between): walk back through global memory
+    uint64_t j = g;
+    while (j > 0) {
+        --j;
+        if ((uint32_t)(j % W) == W - 1u) {
+            continue;
+        }
+        const uint32_t pw = words[j];
+        if (pw != kNoWord) {
+            return colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
+        }
+    }
+    return S;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint32_t* block_sums)
+{
+    __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
+    __shared__ uint32_t s_wave[kThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
+    stage_words(words, base, n_slots, s_w);
+    uint32_t col = (uint32_t)((base + (uint64_t)threadIdx.x * kWPerThread) % W); // one 64-bit division per thread
+    __syncthreads();
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < kWPerThread; k++) {
+        const int li = (int)threadIdx.x * kWPerThread + k;
+        const uint64_t g = base + (uint64_t)li;
+        uint32_t w;
+        if (g < n_slots) {
+            sum += word_length<MODE>(words, s_w, g, li, col, W, w);
+        }
+        col = col + 1u == W ? 0u : col + 1u;
+    }
+    uint32_t total;
+    block_exclusive_scan(sum, s_wave, total);
+    if (threadIdx.x == 0) {
+        block_sums[blockIdx.x] = total;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, const uint32_t* block_sums,
+                                                             uint8_t* out, uint64_t* total_out)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    constexpr uint32_t S = kRgb ? 20u : 12u;
+    __shared__ uint64_t s_part[kThreads / 64];
+    __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
+    __shared__ uint32_t s_digits[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 + kWSlotsPerBlock * S];
+    __shared__ uint32_t s_wave[kThreads / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
+    stage_words(words, base, n_slots, s_w);
+    s_digits[threadIdx.x] = digits_word(threadIdx.x);
+    // where this block's output starts: the sum of the lengths of the blocks before it
+    uint64_t part = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) {
+        part += block_sums[i];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        part += __shfl_xor(part, d);
+    }
+    if ((threadIdx.x & 63u) == 0u) {
+        s_part[threadIdx.x >> 6] = part;
+    }
+    uint32_t col = (uint32_t)((base + (uint64_t)threadIdx.x * kWPerThread) % W);
+    __syncthreads();
+    uint64_t G = 0;
+#pragma unroll
+    for (int k = 0; k < kThreads / 64; k++) {
+        G += s_part[k];
+    }
+    const uint32_t pad = (uint32_t)(G & 15u); // the LDS image is laid out with the same 16-byte phase as its destination
+
+    uint32_t len[kWPerThread], wd[kWPerThread], cols[kWPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kWPerThread; k++) {
+        const int li = (int)threadIdx.x * kWPerThread + k;
+        const uint64_t g = base + (uint64_t)li;
+        len[k] = 0u;
+        wd[k] = kNoWord;
+        cols[k] = col;
+        if (g < n_slots) {
+            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k]);
+        }
+        mine += len[k];
+        col = col + 1u == W ? 0u : col + 1u;
+    }
+    uint32_t n;
+    uint32_t at = pad + block_exclusive_scan(mine, s_wave, n);
+#pragma unroll
+    for (int k = 0; k < kWPerThread; k++) {
+        uint8_t* dst = s_out + at;
+        if (len[k] == S) {
+            Fields f;
+            f.c0 = wd[k] & 255u;
+            f.c1 = (wd[k] >> 8) & 255u;
+            f.c2 = (wd[k] >> 16) & 255u;
+            f.glyph = wd[k] >> 24;
+            uint32_t r[S / 4];
+            record_words<MODE>(wd[k] != kCompactMiss, f, s_digits, r);
+#pragma unroll
+            for (uint32_t q = 0; q < S / 4u; q++) {
+                dst[4 * q + 0] = (uint8_t)(r[q]);
+                dst[4 * q + 1] = (uint8_t)(r[q] >> 8);
+                dst[4 * q + 2] = (uint8_t)(r[q] >> 16);
+                dst[4 * q + 3] = (uint8_t)(r[q] >> 24);
+            }
+        } else if (len[k] == 1u) {
+            // the row's newline, or the glyph alone (the last byte of the record: ' ' for a miss)
+            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (wd[k] == kCompactMiss ? (uint8_t)' ' : (uint8_t)(wd[k] >> 24));
+        }
+        at += len[k];
+    }
+    __syncthreads();
+
+    // copy out: bytes [G, G + n), head and tail of partial 16-byte lines byte by byte, the body as uint4
+    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
+    const uint32_t body16 = (n - head) / 16u;
+    const uint32_t tail = n - head - body16 * 16u;
+    if (threadIdx.x < head) {
+        out[G + threadIdx.x] = s_out[pad + threadIdx.x];
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(s_out + pad + head); // pad + head is 0 mod 16
+    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
+    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
+        dst16[i] = src[i];
+    }
+    if (threadIdx.x < tail) {
+        out[G + head + body16 * 16u + threadIdx.x] = s_out[pad + head + body16 * 16u + threadIdx.x];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        *total_out = G + n; // length of the minimised stream
+    }
+}
+
 } // namespace rtx
 
 namespace {
@@ -422,6 +631,70 @@ int launch_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, co
     }
     RTX_HIP(ctx, hipGetLastError());
     *d_total = total;
+    return RTX_OK;
+}
+
+size_t words_scan_bytes(uint64_t n_slots)
+{
+    const size_t n_blocks = (size_t)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock);
+    return n_blocks * (sizeof(uint32_t) + sizeof(uint64_t)) + 64;
+}
+
+// Minimize from W*H pixel words (every mode but SDL) on the context's stream; scratch laid out as launch_minimize's.
+int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
+{
+    const uint64_t n_slots = (uint64_t)w * h;
+    const unsigned n_blocks = (unsigned)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock);
+    uint64_t* total = (uint64_t*)d_scan;
+    uint64_t* offsets = total + 8;
+    uint32_t* sums = (uint32_t*)(offsets + n_blocks);
+    hipStream_t st = ctx->stream;
+#define RTX_MINW(M)                                                                                                                        \
+    do {                                                                                                                                   \
+        hipLaunchKernelGGL((rtx::rtx_minw_count<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums);      \
+        hipLaunchKernelGGL((rtx::rtx_minw_scatter<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums, d_out, total); \
+    } while (0)
+    switch (mode) {
+    case RTX_BIT_ASCII: RTX_MINW(RTX_K_BIT_ASCII); break;
+    case RTX_BIT_PIXEL: RTX_MINW(RTX_K_BIT_PIXEL); break;
+    case RTX_RGB_ASCII: RTX_MINW(RTX_K_RGB_ASCII); break;
+    case RTX_RGB_PIXEL: RTX_MINW(RTX_K_RGB_PIXEL); break;
+    case RTX_RGB_NORMALS: RTX_MINW(RTX_K_RGB_NORMALS); break;
+    default: return rtx_fail(ctx, RTX_ERR_INVALID_MODE, "no pixel words in this mode");
+    }
+#undef RTX_MINW
+    RTX_HIP(ctx, hipGetLastError());
+    *d_total = total;
+    return RTX_OK;
+}
+
+// Update traces pixel words and minimises from them (the records of the frame are never written) unless the caller asked for
+// the record form (RTX_OPT_UPDATE_WORDS = 0) or the mode has no words (RTX_SDL).
+bool update_from_words(const rtx_ctx* ctx, int mode) { return mode != RTX_SDL && ctx->opt_update_words != 0; }
+
+int ensure_words_buffer(rtx_ctx* ctx, uint32_t** buf, size_t* cap, size_t need)
+{
+    if (*cap >= need) return RTX_OK;
+    if (*buf) {
+        RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(*buf);
+    }
+    *buf = nullptr;
+    *cap = 0;
+    if (hipMalloc((void**)buf, need * sizeof(uint32_t)) != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for the pixel-word buffer");
+    *cap = need;
+    return RTX_OK;
+}
+
+// The frame of `p` as W*H pixel words in *d_words, complete in stream order on the context's stream: sharded over the
+// group's devices and gathered, or one launch into `own` (grown as needed).
+int trace_words(rtx_ctx* ctx, const rtx_params* p, int mode, uint32_t** own, size_t* own_cap, const uint32_t** d_words)
+{
+    if (ctx->group) return rtxgroup::render_words(ctx, p, mode, d_words);
+    int rc = ensure_words_buffer(ctx, own, own_cap, (size_t)p->x * (size_t)p->y);
+    if (rc != RTX_OK) return rc;
+    if ((rc = rtx_render_rows(ctx, p, mode, 0, (size_t)p->y, *own, 0, ctx->stream, RTX_RENDER_COMPACT)) != RTX_OK) return rc;
+    *d_words = *own;
     return RTX_OK;
 }
 
@@ -508,16 +781,57 @@ int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, v
     return RTX_OK;
 }
 
+int rtx_minimize_words(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_words, void* d_out, size_t* out_bytes)
+{
+    if (!ctx || !out_bytes || !d_words) return RTX_ERR_INVALID_ARGUMENT;
+    if (mode < RTX_BIT_ASCII || mode >= RTX_SDL) return rtx_fail(ctx, RTX_ERR_INVALID_MODE, "rtx_minimize_words: not a character mode");
+    if (w == 0 || h == 0 || w >= (1ull << 31) || h >= (1ull << 31)) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "w/h must be in [1, 2^31)");
+    if (((uintptr_t)d_words & 3u) != 0 || (d_out && ((uintptr_t)d_out & 15u) != 0)) {
+        return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_minimize_words: words must be 4-byte, the output 16-byte aligned");
+    }
+    if (!d_out && 20 * w * h > ctx->capacity) return rtx_fail(ctx, RTX_ERR_TOO_LARGE, "minimise output larger than the context's buffer");
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_slots = (uint64_t)w * h;
+    const size_t n_blocks = (size_t)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock);
+    int rc = ensure_min_buffers(ctx, n_blocks, d_out == nullptr);
+    if (rc != RTX_OK) return rc;
+    if (!d_out) d_out = ctx->d_min;
+    uint64_t* d_total = nullptr;
+    if ((rc = launch_minimize_words(ctx, ctx->d_scan, mode, w, h, (const uint32_t*)d_words, (uint8_t*)d_out, &d_total)) != RTX_OK) return rc;
+    uint64_t total = 0;
+    RTX_HIP(ctx, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_bytes = (size_t)total;
+    return RTX_OK;
+}
+
 int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int run_physics, void* host_out, size_t* out_bytes)
 {
     if (!ctx || !params || !host_out || !out_bytes) return RTX_ERR_INVALID_ARGUMENT;
     int rc;
     // RayTracingManager.cu:89-107: physics first
     if (run_physics && (rc = rtx_update_objects(ctx, dt)) != RTX_OK) return rc;
+    size_t n = 0;
+    if (update_from_words(ctx, mode)) {
+        // :120-134 + :146 on 4-byte pixel words: the trace stores words, the minimise pass reads them and writes the very
+        // stream it would have made of the records (which are never written: the context's frame buffer keeps what it held)
+        if (mode < RTX_BIT_ASCII || mode > RTX_SDL) return rtx_fail(ctx, RTX_ERR_INVALID_MODE, "invalid rendering mode");
+        if (params->x == 0 || params->y == 0 || 20 * (uint64_t)params->x * (uint64_t)params->y > ctx->capacity) {
+            return rtx_fail(ctx, params->x && params->y ? RTX_ERR_TOO_LARGE : RTX_ERR_INVALID_ARGUMENT, "frame larger than the context was created for, or empty");
+        }
+        const uint32_t* d_words = nullptr;
+        if ((rc = trace_words(ctx, params, mode, &ctx->d_words, &ctx->words_cap, &d_words)) != RTX_OK) return rc;
+        if ((rc = rtx_minimize_words(ctx, mode, (size_t)params->x, (size_t)params->y, d_words, nullptr, &n)) != RTX_OK) return rc;
+        if (n) {
+            RTX_HIP(ctx, hipMemcpyAsync(host_out, ctx->d_min, n, hipMemcpyDeviceToHost, ctx->stream));
+            RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        *out_bytes = n;
+        return RTX_OK;
+    }
     // :86 + :120-134: zero semantics and trace
     if ((rc = rtx_render(ctx, params, mode)) != RTX_OK) return rc;
     // :146: minimise on the device; :143 then only moves the minimised stream across PCIe
-    size_t n = 0;
     if ((rc = rtx_minimize(ctx, mode, (size_t)params->x, (size_t)params->y, nullptr, nullptr, &n)) != RTX_OK) return rc;
     if (n) {
         RTX_HIP(ctx, hipMemcpyAsync(host_out, ctx->d_min, n, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,7 +856,8 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     if (!ctx->copy_stream) RTX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     // every member under its own null check: a call that fails half-way (out of memory) leaves a slot the next
     // call completes, instead of one that looks initialised with null buffers behind it
-    if (!sl.d_frame) {
+    const bool from_words = update_from_words(ctx, mode);
+    if (!from_words && !sl.d_frame) {
         uint8_t* f = nullptr;
         if (hipMalloc((void**)&f, ctx->capacity) != hipSuccess) return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for an update slot's frame");
         const hipError_t me = hipMemsetAsync(f, 0, ctx->capacity, ctx->stream);
@@ -574,6 +889,13 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     }
     int rc;
     if (run_physics && (rc = rtx_update_objects(ctx, dt)) != RTX_OK) return rc;
+    uint64_t* d_total = nullptr;
+    if (from_words) {
+        // pixel words into the slot's own buffer (a group: into the group's, gathered), minimised from there
+        const uint32_t* d_words = nullptr;
+        if ((rc = trace_words(ctx, params, mode, &sl.d_words, &sl.words_cap, &d_words)) != RTX_OK) return rc;
+        if ((rc = launch_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, sl.d_min, &d_total)) != RTX_OK) return rc;
+    } else {
     // the slot's frame buffer is caller-style memory for rtx_render_rows: whole frame, with the zero
     // semantics of the per-frame memset (the buffer starts zeroed; SDL frames write nothing, so clear)
     const bool rgb = mode >= RTX_RGB_ASCII;
@@ -585,8 +907,8 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     } else if ((rc = rtx_render_rows(ctx, params, mode, 0, h, sl.d_frame, 0, ctx->stream, rgb ? RTX_RENDER_DEFAULT : RTX_RENDER_ZERO_TAIL)) != RTX_OK) {
         return rc;
     }
-    uint64_t* d_total = nullptr;
     if ((rc = launch_minimize(ctx, sl.d_scan, mode, w, h, sl.d_frame, sl.d_min, &d_total)) != RTX_OK) return rc;
+    }
     RTX_HIP(ctx, hipMemcpyAsync(sl.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipEventRecord(sl.ev_ready, ctx->stream));
     // the length is needed on the host to size the copy: wait for this frame's kernels (the previous frame's

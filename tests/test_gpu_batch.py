@@ -111,7 +111,7 @@ def test_mixed_streams_split_into_runs_and_a_graph_replays_the_batch(R):
         for i in range(17):
             assert torch.equal(bufs[i], ref[i]), i
         c.submit_slabs(cams, R.RGB_ASCII, row0, rows, [b.data_ptr() for b in bufs], row0, [s0.cuda_stream] * 17, flags=R.RENDER_COMPACT)
-        assert c.get_option(R.STAT_BATCHED_LAUNCHES) == k0 + 5          # 16 + 1
+        assert c.get_option(R.STAT_BATCHED_LAUNCHES) == k0 + 4          # 16 in one batched launch + 1 plain launch
         torch.cuda.synchronize()
         # a recorded round
         c.graph_begin(main.cuda_stream)

@@ -415,3 +415,83 @@ def test_hip_graph_replays_a_round_of_slabs_and_their_expansion(R, ctx):
     queue_round()
     torch.cuda.synchronize()
     assert np.array_equal(recs.cpu().numpy(), want)
+
+
+# ---- Minimize from compact pixel words (rtx_minimize_words; what rtx_update runs by default, RTX_OPT_UPDATE_WORDS)
+
+@pytest.mark.parametrize("mode", range(5))
+@pytest.mark.parametrize("res", [(400, 150), (97, 41), (1, 5), (2, 7), (3, 3), (1030, 9)])
+def test_minimize_from_words_is_minimize_of_the_records(R, ctx, res, mode):
+    """The words the trace kernel stores (RTX_RENDER_COMPACT) through rtx_minimize_words against the oracle's Minimize8bit /
+    MinimizeRGB (RayTracingManager.cu:181-319) of the oracle's frame: same bytes, same length."""
+    import torch
+    w, h = res
+    ctx.set_reference_default_scene()
+    p = R.camera_params(w, h)
+    words = torch.empty(w * h, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(20 * w * h + 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_rows(p, mode, 0, h, d_out=words.data_ptr(), out_row_base=0, flags=R.RENDER_COMPACT)
+    ctx.synchronize()
+    n = ctx.minimize_words(mode, w, h, words.data_ptr(), d_out=dst.data_ptr())
+    want = O.minimize(mode, O.render(U.oracle_params(p), O.Scene.reference_default(), mode), w, h)
+    assert n == want.size and np.array_equal(dst.cpu().numpy()[:n], want)
+
+
+def test_minimize_from_words_with_empty_slots_and_rows(R, ctx):
+    """Words of a frame that was only partly rendered (0xffffffff = an empty slot: NUL as a record): colour persistence skips
+    the empty slots, across rows and across blocks of the pass, exactly as the byte scan does on the expanded records."""
+    import torch
+    w, h = 300, 40
+    ctx.set_reference_default_scene()
+    p = R.camera_params(w, h)
+    rng = np.random.default_rng(5)
+    for mode in (R.RGB_ASCII, R.BIT_PIXEL):
+        S = 20 if mode >= R.RGB_ASCII else 12
+        words = torch.empty(w * h, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.render_rows(p, mode, 0, h, d_out=words.data_ptr(), out_row_base=0, flags=R.RENDER_COMPACT)
+        ctx.synchronize()
+        hw = words.cpu().numpy().view(np.uint32).copy().reshape(h, w)
+        hw[3:9, :] = 0xFFFFFFFF                          # whole rows empty (longer than a block of the pass: 6 x 300 > 1024)
+        hw[20, 5:290] = 0xFFFFFFFF                       # most of a row
+        holes = rng.random((h, w)) < 0.3
+        holes[:, w - 1] = False
+        hw[holes] = 0xFFFFFFFF
+        hw[0, 0] = 0xFFFFFFFF                            # the frame's first slot
+        words.copy_(torch.from_numpy(hw.reshape(-1).view(np.int32)))
+        dst = torch.zeros(20 * w * h, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        n = ctx.minimize_words(mode, w, h, words.data_ptr(), d_out=dst.data_ptr())
+        frame = np.zeros(20 * w * h, dtype=np.uint8)
+        frame[:S * w * h] = U.words_to_records(hw.reshape(-1), S, ord("3") if mode in (R.RGB_ASCII, R.BIT_ASCII) else ord("4"))
+        want = O.minimize(mode, frame, w, h)
+        assert n == want.size and np.array_equal(dst.cpu().numpy()[:n], want), R.MODE_NAMES[mode]
+
+
+def test_update_from_words_and_from_records_hand_over_the_same_stream(R):
+    """rtx_update traces pixel words and minimises from them by default (RTX_OPT_UPDATE_WORDS): the stream is the golden one
+    (C2, both record sizes) and the frame buffer is left alone; with the option off the records are written and minimised, as
+    the reference does, and the frame buffer holds the frame."""
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H) as c:
+        c.set_scene(sph, pl)
+        assert c.get_option(R.OPT_UPDATE_WORDS) == -1
+        for mode in (R.RGB_ASCII, R.BIT_ASCII):
+            g = gold["C2_%s" % R.MODE_NAMES[mode]]
+            got = c.update(p, mode)
+            assert "compact" in c.last_kernel
+            assert len(got) == g["minimized_bytes"] and O.fnv1a64(got) == g["minimized_fnv1a64"]
+        assert not c.read_frame(20 * W * H).any()                      # never written
+        c.set_option(R.OPT_UPDATE_WORDS, 0)
+        for mode in (R.RGB_ASCII, R.BIT_ASCII):
+            g = gold["C2_%s" % R.MODE_NAMES[mode]]
+            got = c.update(p, mode)
+            assert "compact" not in c.last_kernel
+            assert len(got) == g["minimized_bytes"] and O.fnv1a64(got) == g["minimized_fnv1a64"]
+            assert O.fnv1a64(c.read_frame(20 * W * H)) == g["frame_fnv1a64"]
+        # SDL has no words: one newline per row either way
+        c.set_option(R.OPT_UPDATE_WORDS, -1)
+        assert bytes(c.update(p, R.SDL)) == b"\n" * H

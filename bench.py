@@ -202,6 +202,8 @@ def parse_args(argv=None):
     ap.add_argument("--what", default="trace", choices=["trace", "update", "update-async"],
                     help="trace: the graded step (frame resident in HBM). update: whole RayTracingManager::Update "
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
+    ap.add_argument("--update-records", action="store_true",
+                    help="--what update: the record form of Update (RTX_OPT_UPDATE_WORDS = 0: records written, then minimised) instead of the default word form")
     ap.add_argument("--physics", action="store_true", help="--what update: run the UpdateObjects step (dt 0.016) in every Update, as the reference does")
     ap.add_argument("--native", action="store_true",
                     help="N GPUs in ONE process, no torchrun: a device group behind the C ABI (rtx_group_create: row slabs traced on N devices, "
@@ -209,6 +211,9 @@ def parse_args(argv=None):
     ap.add_argument("--native-devices", default=None,
                     help="--native: the device list, e.g. 0,0,0,0 (an ordinal may repeat: several logical ranks on one GPU, how a one-GPU "
                          "box walks N = 4); default 0 .. N-1")
+    ap.add_argument("--native-frames", type=int, default=8,
+                    help="--native: frames per rtx_submit_frames call (every rank traces its rows of that many frames with one batched launch, "
+                         "the slabs travel together); 1 = rtx_render, a frame per call")
     ap.add_argument("--native-wire", default="compact", choices=["compact", "records"], help="--native: what the slabs travel as")
     ap.add_argument("--no-native-leg", action="store_true", help="N>1: skip the native_group sub-record rank 0 measures after the ranks are done")
     ap.add_argument("--dry", action="store_true",
@@ -406,6 +411,8 @@ def run_single(args, torch, R):
     ctx = R.Context(W, H, device=0)
     ctx.set_scene(sph, pl)
     apply_options(R, ctx, args)
+    if args.update_records:
+        ctx.set_option(R.OPT_UPDATE_WORDS, 0)
     ctx.render_rows(params, mode, 0, 1)   # uploads the scene
     ctx.synchronize()
     if args.frames_in_flight <= 0:
@@ -740,32 +747,47 @@ def run_native(args, torch, R, devices, config, K, Wm, prewarm_ms, update_leg=Tr
         ctx.set_option(R.OPT_GROUP_WIRE, R.WIRE_RECORDS if args.native_wire == "records" else R.WIRE_COMPACT)
         ctx.render(params, mode)
         ctx.synchronize()
+        M = max(1, min(args.native_frames, 16, K))
+        fbufs = None
+        if M > 1:
+            # M frames per call into M frame buffers on the root's device (rtx_submit_frames on the group)
+            fbufs = [torch.zeros(20 * W * H, dtype=torch.uint8, device="cuda:%d" % devices[0]) for _ in range(M)]
+            torch.cuda.synchronize()
+            sub = ctx.make_submitter(params, mode, [b.data_ptr() for b in fbufs], [None] * M)
+
+        def frames(count):
+            if M == 1:
+                for _ in range(count):
+                    ctx.render(params, mode)
+            else:
+                done = 0
+                while done < count:
+                    sub(min(M, count - done), 0)
+                    done += min(M, count - done)
+
         t0 = time.perf_counter()
         while (time.perf_counter() - t0) * 1e3 < prewarm_ms:
-            for _ in range(32):
-                ctx.render(params, mode)
+            frames(32)
             ctx.synchronize()
-        for _ in range(Wm):
-            ctx.render(params, mode)
+        frames(Wm)
         ctx.synchronize()
         evs, walls = [], []
         while True:
             tw = time.perf_counter()
             ctx.timer_start()
-            for _ in range(K):
-                ctx.render(params, mode)
+            frames(K)
             evs.append(ctx.timer_stop())
             walls.append((time.perf_counter() - tw) * 1e3)
             if len(evs) >= min(args.max_repeats, 200) or (sum(evs) >= args.min_timed_ms and len(evs) >= 3):
                 break
         batch_ms = median(evs)
-        frame = ctx.read_frame(20 * W * H)
+        frame = ctx.read_frame(20 * W * H) if M == 1 else fbufs[(K - 1) % M if K % M else M - 1].cpu().numpy()
         verified = None if args.no_verify else _frame_matches_golden(frame, config, args.mode)
         rays = (W - 1) * H
         rec = {"value": round(rays * K / (batch_ms * 1e-3) / 1e6, 3), "unit": "Mrays/s", "n_gpus": len(set(devices)), "logical_ranks": n,
                "steps": K, "warmup": Wm, "ms_per_step": round(batch_ms / K, 5),
                "config": {"workload": "%s: %dx%d, %d spheres + %d planes, mode %s, SURVEY App. D scene seed %d" % (config, W, H, ns, npl, args.mode, seed),
-                          "rays_per_frame": rays, "devices": list(devices),
+                          "rays_per_frame": rays, "devices": list(devices), "frames_per_call": M,
                           "rows_per_rank": [ctx.group_rows(H, r)[1] for r in range(n)],
                           "parallelism": "device group behind the C ABI (rtx_group_create): one process, %d logical rank(s) on %d device(s), rows "
                                          "sharded, slabs gathered on device %d as %s; exchange: %s"

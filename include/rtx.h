@@ -199,7 +199,11 @@ void rtx_destroy(rtx_ctx* ctx);
  *   rtx_scene_* / rtx_update_objects / rtx_set_option   apply to every rank's replica of the scene (<= 6.8 MB, replicated),
  *   rtx_render, rtx_update, rtx_update_begin / _end      trace sharded and deliver on the root exactly what they deliver on one
  *                                                        device (frame buffer, minimised stream),
- *   rtx_render_rows, rtx_submit_*, rtx_expand, rtx_minimize, graphs   act on the root's device alone (caller's buffers there),
+ *   rtx_submit_frames                                    n whole frames, sharded: every rank traces its rows of up to 16 frames with one
+ *                                                        launch (RTX_OPT_BATCH) and the slabs of the chunk travel together -- the form
+ *                                                        for throughput; the frames are complete in stream order on the context's own
+ *                                                        stream, which the streams[i] given are made to wait for,
+ *   rtx_render_rows, rtx_submit_slabs, rtx_expand, rtx_minimize, graphs   act on the root's device alone (caller's buffers there),
  *   rtx_destroy                                          releases the whole group.
  * The reference's single consumer, RayTracingManager::Update (RayTracingManager.cu:76-154, hand-off at :150), therefore
  * runs unchanged over N GPUs: include/rtx_compat.hpp takes the device list from RTX_DEVICES or Device::set_devices().

@@ -23,6 +23,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -84,6 +85,7 @@ struct rtx_group {
     std::vector<rtx_ctx*> member; // [0] = the root (owned by the caller)
     std::vector<int> device;
     bool distinct = true;         // no device appears twice in the list
+    std::vector<char> direct;     // per rank: its device and the root's address each other's memory (same device, or peer access enabled)
     std::vector<hipEvent_t> ev_done; // per rank, on its device: its slab has arrived on the root (peer copies)
     hipEvent_t ev_free = nullptr;    // root's device: the destination may be overwritten
     uint32_t* d_words = nullptr;     // root's device: the frame as compact words (W * H)
@@ -405,6 +407,142 @@ int render_frame(rtx_ctx* root, const rtx_params* p, int mode, void* d_out, unsi
     return rtx_expand(root, mode, g->d_words, own ? (void*)root->d_frame : d_out, &seg, 1, root->stream);
 }
 
+// n whole frames, sharded, into d_outs[i] (records, on the root's device): every rank traces its rows of a chunk of frames
+// with ONE call (rtx_submit_slabs on its member context: one batched launch where the plan allows, RTX_OPT_BATCH), the slabs
+// of the chunk are gathered, the root expands.  The host cost per frame of a sharded launch-by-launch loop (a launch, a copy
+// and two events per rank and frame: ~15 us per rank on the caller's one thread) is paid once per chunk instead.
+int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, void* const* d_outs, void* const* streams)
+{
+    rtx_group* g = root->group;
+    const int N = g->n;
+    int rc;
+    for (size_t i = 0; i < n; i++) {
+        if ((rc = validate_frame(root, &params[i], mode)) != RTX_OK) return rc;
+        if (!d_outs[i] || ((uintptr_t)d_outs[i] & 3u) != 0) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "rtx_submit_frames: null or misaligned frame buffer");
+    }
+    bool uniform = mode != RTX_SDL && N > 1;
+    for (size_t i = 1; i < n && uniform; i++) {
+        uniform = params[i].x == params[0].x && params[i].y == params[0].y;
+    }
+    if (!uniform) {
+        // frames of different sizes (or nothing to shard): one by one
+        for (size_t i = 0; i < n; i++) {
+            if ((rc = render_frame(root, &params[i], mode, d_outs[i], RTX_RENDER_DEFAULT)) != RTX_OK) return rc;
+        }
+    } else {
+        const uint64_t W = params[0].x, H = params[0].y;
+        const bool compact = wire_is_compact(g);
+        const uint64_t S = compact ? 4u : (mode >= RTX_RGB_ASCII ? 20u : 12u);
+        const unsigned slab_flags = compact ? (unsigned)RTX_RENDER_COMPACT : (unsigned)RTX_RENDER_DEFAULT;
+        // frames per chunk: what the batched kernel takes, and what the ranks' slab buffers (their frame buffers) hold
+        size_t chunk = 16;
+        for (int r = 1; r < N; r++) {
+            const uint64_t rows = bound(H, r + 1, N) - bound(H, r, N);
+            if (rows) chunk = std::min<size_t>(chunk, (size_t)(g->member[(size_t)r]->capacity / (rows * W * S)));
+        }
+        if (chunk == 0) return rtx_fail(root, RTX_ERR_TOO_LARGE, "frame larger than the group was created for");
+        const bool use_rccl = rccl_wanted(g) && g->opt_exchange != RTX_EXCHANGE_RCCL_ALL && rccl_ready(root, g);
+        g->exchange_in_use = use_rccl ? RTX_EXCHANGE_RCCL : RTX_EXCHANGE_PEER_COPY;
+        std::vector<void*> ptrs(chunk), strs(chunk);
+        for (size_t first = 0; first < n; first += chunk) {
+            const size_t m = std::min(chunk, n - first);
+            if (compact && (rc = ensure_words(root, g, W, H * m)) != RTX_OK) return rc;
+            // where frame i of the chunk is assembled: its words in the group's buffer, or its records in the caller's
+            auto dest = [&](size_t i) { return compact ? (uint8_t*)(g->d_words + i * W * H) : (uint8_t*)d_outs[first + i]; };
+            for (int r = 1; r < N; r++) {
+                const uint64_t r0 = bound(H, r, N), rows = bound(H, r + 1, N) - r0;
+                if (rows == 0) continue;
+                rtx_ctx* mem = g->member[(size_t)r];
+                for (size_t i = 0; i < m; i++) {
+                    ptrs[i] = mem->d_frame + i * rows * W * S;
+                    strs[i] = mem->stream;
+                }
+                if ((rc = rtx_submit_slabs(mem, m, &params[first], mode, (size_t)r0, (size_t)rows, ptrs.data(), (size_t)r0, strs.data(), nullptr, slab_flags)) != RTX_OK) {
+                    return member_fail(root, r, mem, rc);
+                }
+                mem->dirty_hi = mem->capacity;
+            }
+            {
+                const uint64_t rows0 = bound(H, 1, N);
+                for (size_t i = 0; i < m; i++) {
+                    ptrs[i] = dest(i);
+                    strs[i] = root->stream;
+                }
+                if (rows0 && (rc = rtx_submit_slabs(root, m, &params[first], mode, 0, (size_t)rows0, ptrs.data(), 0, strs.data(), nullptr, slab_flags)) != RTX_OK) return rc;
+            }
+            uint64_t moved = 0;
+            if (use_rccl) {
+                RcclApi* api = rccl_api(nullptr);
+                ncclResult_t nrc = api->GroupStart();
+                for (int r = 1; r < N && nrc == ncclSuccess; r++) {
+                    const uint64_t r0 = bound(H, r, N), rows = bound(H, r + 1, N) - r0;
+                    if (rows == 0) continue;
+                    rtx_ctx* mem = g->member[(size_t)r];
+                    const size_t bytes = (size_t)(rows * W * S);
+                    for (size_t i = 0; i < m && nrc == ncclSuccess; i++) {
+                        nrc = api->Send(mem->d_frame + i * bytes, bytes, ncclChar, 0, g->comms[(size_t)r], mem->stream);
+                        if (nrc == ncclSuccess) nrc = api->Recv(dest(i) + r0 * W * S, bytes, ncclChar, r, g->comms[0], root->stream);
+                        moved += bytes;
+                    }
+                }
+                const ncclResult_t erc = api->GroupEnd();
+                if (nrc == ncclSuccess) nrc = erc;
+                if (nrc != ncclSuccess) return rtx_fail(root, RTX_ERR_HIP, std::string("RCCL exchange failed: ") + (api->GetErrorString ? api->GetErrorString(nrc) : "?"));
+                RTX_HIP(root, hipSetDevice(root->device));
+            } else {
+                RTX_HIP(root, hipSetDevice(root->device));
+                RTX_HIP(root, hipEventRecord(g->ev_free, root->stream));
+                for (int r = 1; r < N; r++) {
+                    const uint64_t r0 = bound(H, r, N), rows = bound(H, r + 1, N) - r0;
+                    if (rows == 0) continue;
+                    rtx_ctx* mem = g->member[(size_t)r];
+                    const size_t bytes = (size_t)(rows * W * S);
+                    RTX_HIP(root, hipSetDevice(mem->device));
+                    RTX_HIP(root, hipStreamWaitEvent(mem->stream, g->ev_free, 0));
+                    if (compact && m > 1 && g->direct[(size_t)r]) {
+                        // the chunk's slabs lie back to back in the rank's buffer and H*W words apart on the root: one strided copy
+                        RTX_HIP(root, hipMemcpy2DAsync(dest(0) + r0 * W * S, (size_t)(H * W * S), mem->d_frame, bytes, bytes, m, hipMemcpyDeviceToDevice, mem->stream));
+                    } else {
+                        for (size_t i = 0; i < m; i++) {
+                            RTX_HIP(root, hipMemcpyPeerAsync(dest(i) + r0 * W * S, root->device, mem->d_frame + i * bytes, mem->device, bytes, mem->stream));
+                        }
+                    }
+                    RTX_HIP(root, hipEventRecord(g->ev_done[(size_t)r], mem->stream));
+                    moved += bytes * m;
+                }
+                RTX_HIP(root, hipSetDevice(root->device));
+                for (int r = 1; r < N; r++) {
+                    if (bound(H, r + 1, N) - bound(H, r, N) == 0) continue;
+                    RTX_HIP(root, hipStreamWaitEvent(root->stream, g->ev_done[(size_t)r], 0));
+                }
+            }
+            g->stat_gathers += m;
+            g->stat_last_bytes = moved / m;
+            if (compact) {
+                for (size_t i = 0; i < m; i++) {
+                    const rtx_segment seg = {0u, 0u, W * H};
+                    if ((rc = rtx_expand(root, mode, g->d_words + i * W * H, d_outs[first + i], &seg, 1, root->stream)) != RTX_OK) return rc;
+                }
+            }
+        }
+    }
+    // the caller's streams see the frames once the root's stream has them
+    bool any = false;
+    for (size_t i = 0; i < n; i++) any = any || (streams && streams[i] && (hipStream_t)streams[i] != root->stream);
+    if (any) {
+        RTX_HIP(root, hipSetDevice(root->device));
+        RTX_HIP(root, hipEventRecord(g->ev_done[0], root->stream));
+        for (size_t i = 0; i < n; i++) {
+            hipStream_t s = (hipStream_t)streams[i];
+            if (!s || s == root->stream) continue;
+            bool seen = false;
+            for (size_t k = 0; k < i; k++) seen = seen || streams[k] == streams[i];
+            if (!seen) RTX_HIP(root, hipStreamWaitEvent(s, g->ev_done[0], 0));
+        }
+    }
+    return RTX_OK;
+}
+
 int render_words(rtx_ctx* root, const rtx_params* p, int mode, const uint32_t** d_words)
 {
     rtx_group* g = root->group;
@@ -457,18 +595,28 @@ int rtx_group_create(int ndev, const int* devices, size_t max_w, size_t max_h, r
     }
     // direct access between the root's device and every other one, both ways, where the hardware offers it (xGMI):
     // hipMemcpyPeerAsync then moves the bytes GPU to GPU instead of staging them through the host
+    g->direct.assign((size_t)ndev, 1);
     for (int r = 1; r < ndev; r++) {
         const int a = g->device[0], b = g->device[(size_t)r];
         if (a == b) continue;
-        int can = 0;
-        if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+        int can_ab = 0, can_ba = 0;
+        bool ok = true;
+        if (hipDeviceCanAccessPeer(&can_ab, a, b) == hipSuccess && can_ab) {
             hipSetDevice(a);
-            if (hipDeviceEnablePeerAccess(b, 0) != hipSuccess) (void)hipGetLastError(); // (already enabled: fine)
+            const hipError_t e = hipDeviceEnablePeerAccess(b, 0);
+            ok = ok && (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+        } else {
+            ok = false;
         }
-        if (hipDeviceCanAccessPeer(&can, b, a) == hipSuccess && can) {
+        if (hipDeviceCanAccessPeer(&can_ba, b, a) == hipSuccess && can_ba) {
             hipSetDevice(b);
-            if (hipDeviceEnablePeerAccess(a, 0) != hipSuccess) (void)hipGetLastError();
+            const hipError_t e = hipDeviceEnablePeerAccess(a, 0);
+            ok = ok && (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled);
+        } else {
+            ok = false;
         }
+        (void)hipGetLastError();
+        g->direct[(size_t)r] = ok ? 1 : 0; // (without it hipMemcpyPeerAsync still works, staged by the runtime; strided copies are not used)
     }
     (void)hipGetLastError();
     hipSetDevice(g->device[0]);

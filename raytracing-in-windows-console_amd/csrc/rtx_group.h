@@ -30,6 +30,8 @@ int update_objects(rtx_ctx* root, double dt); // every member steps its own repl
 // The whole frame of `p`, sharded over the members, as RECORDS in d_out on the root's device (nullptr: the root's own frame
 // buffer, with its zero-fill bookkeeping), complete in stream order on the root's stream.
 int render_frame(rtx_ctx* root, const rtx_params* p, int mode, void* d_out, unsigned flags);
+// n whole frames (rtx_submit_frames on a group): every rank traces its rows of all of them with one call, one gather per chunk.
+int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, void* const* d_outs, void* const* streams);
 // ... as compact pixel words (W * H of them, include/rtx.h RTX_RENDER_COMPACT) in the group's word buffer on the root's device,
 // complete in stream order on the root's stream; *d_words receives the buffer.  What rtx_update minimises from.
 int render_words(rtx_ctx* root, const rtx_params* p, int mode, const uint32_t** d_words);

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, u
 //     (bytes 7-9 [, 11-13, 15-17] of the record: the decimal digits) is a function of the word's colour bytes alone -- the
 //     digits of (r, g, b) or of the xterm index; a miss carries the digits of (0, 0, 0) resp. of index 16 (App. B) -- so
 //     "same colour digits" is "same colour key".
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
 constexpr int kWPerThread = 4;
 constexpr int kWSlotsPerBlock = kThreads * kWPerThread; // 1024 slots = 4 KB of words per block
 constexpr uint32_t kNoWord = 0xffffffffu;               // = kCompactNewline
@@ -485,39 +486,54 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __res
     }
 }
 
+// The blocks' sums -> their offsets in the stream (exclusive scan; one workgroup, 2048 sums per step) and the stream's length.
+// A launch of its own between the two passes: the scatter pass then finds its place with one load, where summing the preceding
+// blocks' sums in every block cost a chain of dependent L2 round trips per block and O(blocks^2) loads per frame (32 400 blocks
+// at 8K).  (Letting the count pass's last block do this -- a ticket drawn with atomicAdd -- was measured: 2025 device-scope
+// atomics on one address take 46 us, 22 ns each.)
+__global__ __launch_bounds__(kThreads) void rtx_min_offsets(const uint32_t* __restrict__ block_sums, uint32_t nb, uint64_t* __restrict__ offsets, uint64_t* total_out)
+{
+    __shared__ uint32_t s_wave[kThreads / 64];
+    uint64_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 8u * kThreads) {
+        uint32_t v[8], mine = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) {
+            const uint32_t i = b0 + threadIdx.x * 8u + q;
+            v[q] = i < nb ? block_sums[i] : 0u;
+            mine += v[q];
+        }
+        uint32_t step_total;
+        uint64_t at = carry + block_exclusive_scan(mine, s_wave, step_total);
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; q++) {
+            const uint32_t i = b0 + threadIdx.x * 8u + q;
+            if (i < nb) offsets[i] = at;
+            at += v[q];
+        }
+        carry += step_total;
+    }
+    if (threadIdx.x == 0) {
+        *total_out = carry; // length of the minimised stream
+    }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, const uint32_t* block_sums,
-                                                             uint8_t* out, uint64_t* total_out)
+__global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, const uint64_t* __restrict__ offsets,
+                                                             uint8_t* out)
 {
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
     constexpr uint32_t S = kRgb ? 20u : 12u;
-    __shared__ uint64_t s_part[kThreads / 64];
     __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
     __shared__ uint32_t s_digits[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[16 + kWSlotsPerBlock * S];
     __shared__ uint32_t s_wave[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
+    const uint64_t G = offsets[blockIdx.x]; // where this block's output starts (the count pass's last block left it)
     stage_words(words, base, n_slots, s_w);
     s_digits[threadIdx.x] = digits_word(threadIdx.x);
-    // where this block's output starts: the sum of the lengths of the blocks before it
-    uint64_t part = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) {
-        part += block_sums[i];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        part += __shfl_xor(part, d);
-    }
-    if ((threadIdx.x & 63u) == 0u) {
-        s_part[threadIdx.x >> 6] = part;
-    }
     uint32_t col = (uint32_t)((base + (uint64_t)threadIdx.x * kWPerThread) % W);
     __syncthreads();
-    uint64_t G = 0;
-#pragma unroll
-    for (int k = 0; k < kThreads / 64; k++) {
-        G += s_part[k];
-    }
     const uint32_t pad = (uint32_t)(G & 15u); // the LDS image is laid out with the same 16-byte phase as its destination
 
     uint32_t len[kWPerThread], wd[kWPerThread], cols[kWPerThread], mine = 0;
@@ -547,12 +563,11 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __r
             f.glyph = wd[k] >> 24;
             uint32_t r[S / 4];
             record_words<MODE>(wd[k] != kCompactMiss, f, s_digits, r);
+            // the record lands at an arbitrary byte offset of the LDS image: dword stores without an alignment promise (gfx950
+            // takes unaligned LDS accesses: one ds_write_b32 each, where byte stores were twenty)
 #pragma unroll
             for (uint32_t q = 0; q < S / 4u; q++) {
-                dst[4 * q + 0] = (uint8_t)(r[q]);
-                dst[4 * q + 1] = (uint8_t)(r[q] >> 8);
-                dst[4 * q + 2] = (uint8_t)(r[q] >> 16);
-                dst[4 * q + 3] = (uint8_t)(r[q] >> 24);
+                *reinterpret_cast<u32_unaligned*>(dst + 4u * q) = r[q];
             }
         } else if (len[k] == 1u) {
             // the row's newline, or the glyph alone (the last byte of the record: ' ' for a miss)
@@ -577,9 +592,6 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __r
     if (threadIdx.x < tail) {
         out[G + head + body16 * 16u + threadIdx.x] = s_out[pad + head + body16 * 16u + threadIdx.x];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        *total_out = G + n; // length of the minimised stream
-    }
 }
 
 } // namespace rtx
@@ -599,6 +611,7 @@ int ensure_min_buffers(rtx_ctx* ctx, size_t n_blocks, bool need_out)
             return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for the minimise scratch");
         }
         ctx->scan_bytes = need;
+
     }
     if (need_out && !ctx->d_min) {
         // m_minimizedResultArray is as large as the frame (RayTracingManager.cu:66)
@@ -652,7 +665,8 @@ int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
 #define RTX_MINW(M)                                                                                                                        \
     do {                                                                                                                                   \
         hipLaunchKernelGGL((rtx::rtx_minw_count<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums);      \
-        hipLaunchKernelGGL((rtx::rtx_minw_scatter<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums, d_out, total); \
+        hipLaunchKernelGGL(rtx::rtx_min_offsets, dim3(1), dim3(rtx::kThreads), 0, st, sums, n_blocks, offsets, total);                      \
+        hipLaunchKernelGGL((rtx::rtx_minw_scatter<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, offsets, d_out); \
     } while (0)
     switch (mode) {
     case RTX_BIT_ASCII: RTX_MINW(RTX_K_BIT_ASCII); break;

@@ -206,3 +206,39 @@ def test_reference_api_surface_over_a_group(R, tmp_path):
         want = O.minimize(mode, frame, 400, 150)
         for got in outs:
             assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("ranks,wire", [(8, "compact"), (4, "records"), (3, "compact")])
+def test_submit_frames_on_a_group_shards_a_chunk_of_frames_per_call(R, ranks, wire):
+    """rtx_submit_frames on a group: n whole frames with n cameras, every rank tracing its rows of all of them with ONE batched
+    launch (RTX_OPT_BATCH) and the chunk's slabs travelling together; each frame equals the frame a single device renders for
+    that camera.  18 frames: more than one chunk (16 at most per launch)."""
+    import torch
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    n = 18
+    cams = [R.camera_params(W, H, pos=(0.3 * i, 0.1 * i, -0.2 * i), rot=(0.004 * i, float(np.float32(np.pi)) + 0.01 * i, 0.0)) for i in range(n)]
+    bufs = [torch.empty(20 * W * H, dtype=torch.uint8, device="cuda") for _ in range(n)]
+    side = torch.cuda.Stream()
+    with R.Context(W, H) as one:
+        one.set_scene(sph, pl)
+        want = [O.fnv1a64(one.render_to_host(c, R.RGB_ASCII)) for c in cams]
+    with R.Context(W, H, devices=[0] * ranks) as g:
+        g.set_option(R.OPT_GROUP_WIRE, R.WIRE_COMPACT if wire == "compact" else R.WIRE_RECORDS)
+        g.set_scene(sph, pl)
+        for rep in range(2):
+            for b in bufs:
+                b.fill_(0xEE)
+            torch.cuda.synchronize()
+            g.submit_frames(cams, R.RGB_ASCII, [b.data_ptr() for b in bufs], [side.cuda_stream] * n)
+            side.synchronize()          # the caller's stream was made to wait for the frames
+            for i in range(n):
+                assert O.fnv1a64(bufs[i].cpu().numpy()) == want[i], (rep, i)
+        # every rank used the batched kernel, a launch per chunk: 16 frames at most, and what a rank's slab buffer (its 20*W*H
+        # frame buffer) holds of 4-byte words or 20-byte records
+        S = 4 if wire == "compact" else 20
+        chunk = min([16] + [(20 * H) // (g.group_rows(H, r)[1] * S) for r in range(1, ranks)])
+        per_call = sum(1 for c0 in range(0, n, chunk) if min(chunk, n - c0) >= 2)
+        for r in range(ranks):
+            assert g.member_option(r, R.STAT_BATCHED_LAUNCHES) == 2 * per_call, (r, chunk, g.member_kernel(r))
+        assert g.get_option(R.STAT_GROUP_GATHERS) == 2 * n

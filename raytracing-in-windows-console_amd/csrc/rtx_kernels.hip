@@ -376,16 +376,19 @@ constexpr int kMaxMacroRefine = 64; // ... 64 x 64 for the REFINE kernels
 constexpr int kChunk = 2 * kThreads; // spheres staged per barrier: two per thread
 constexpr int kPlaneTable = 16;   // planes hoisted into LDS; further planes take the direct path
 
+constexpr uint32_t kStageFull = 0xffffffffu; // stage_chunk: the step's survivors would not fit the list (nothing was written)
+
 // One staging step: items [base, base + 512) of `ns` items, two per thread.  g0/g1 (sphere indices k0/k1)
 // are this thread's geometry records, already loaded: the caller prefetches the next step's first.  Hoists the
 // ray-independent terms, culls, and appends survivors to the LDS list in index order (wave ballots,
-// per-wave counts through LDS, one barrier).  Returns the new list length (uniform).
+// per-wave counts through LDS, one barrier).  Returns the new list length (uniform), or kStageFull when the step's
+// survivors would take the list past `cap` entries (then nothing is written).
 // (Keeping the geometry and colour records of the first list entries in LDS, so that a pass takes its winner's records
 // from there instead of a round trip to memory, was measured and dropped: no gain, profiles/r02_c_single_launch_experiments.md.)
 template <bool CULL>
 __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFrustum& fr, uint32_t ns, uint32_t base, float4 g0, float4 g1,
                                                 uint32_t k0, uint32_t k1, float4* s_rec, uint32_t* s_idx, uint32_t (*s_wcnt)[8],
-                                                uint32_t parity, uint32_t total, bool drop_all, float* s_margin = nullptr)
+                                                uint32_t parity, uint32_t total, bool drop_all, uint32_t cap, float* s_margin = nullptr)
 {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     bool keep[2];
@@ -434,6 +437,11 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         sum += c;
         if (w < wave) before += c; // first halves of earlier waves (wave <= 3)
     }
+    // a step whose survivors do not fit the list is not written at all (uniform: every thread sees the same counts)
+    const uint32_t grown = __builtin_amdgcn_readfirstlane(total + sum);
+    if (grown > cap) {
+        return kStageFull;
+    }
     // index order: [first-half survivors of waves 0..3][second-half survivors of waves 0..3]
     uint32_t first_total = 0, before1 = 0;
 #pragma unroll
@@ -454,7 +462,7 @@ __device__ __forceinline__ uint32_t stage_chunk(const Camera& cam, const TileFru
         s_idx[pos] = k1;
         if (s_margin) s_margin[pos] = mg[1];
     }
-    return __builtin_amdgcn_readfirstlane(total + sum);
+    return grown;
 }
 
 // The spheres a workgroup stages: all of them (list == nullptr), or the index list its coarse cell

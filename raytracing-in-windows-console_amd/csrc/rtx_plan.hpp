@@ -189,6 +189,7 @@ struct TileRequest {
     int opt_tile_log2w = 0;          // RTX_OPT_TILE_LOG2_W (0 = choose)
     int opt_refine = -1;             // RTX_OPT_REFINE (-1 auto)
     bool view_dense = false;         // the launches before this one saw long candidate lists (ViewDensity): plan as for a dense scene
+    bool in_flight = false;          // the caller keeps frames in flight on several streams: throughput counts, not one launch's latency
 };
 
 struct TileShape {
@@ -217,6 +218,12 @@ inline TileShape plan_tiles(const TileRequest& q)
         nsub = q.opt_subtiles;
     } else if (q.cull) {
         nsub = density >= kDenseScene ? 2 : (t.tiles256 >= 24000u ? 8 : 4); // (config 3, 32 400 tiles: 90.3 -> 85.2 us per frame in flight with 8, alone the same)
+        // A scene that is dense by its numbers, frames in flight: 4 sub-tiles.  The kernel is then bound by VALU issue (config 5:
+        // 0.91 of what the SIMDs can issue), and a workgroup's set-up -- tile, cell list, tables, pyramids, staging: 226 of 826 VALU
+        // instructions per pixel-wave with 2 sub-tiles -- is shared by twice the pixels: 826 -> 762 instructions, 32.6 -> 28.8 us
+        // per frame with 6 in flight.  One launch alone is bound by the workgroups' latency instead and loses (41.6 -> 43.9 us: half
+        // as many workgroups, each twice as long), so a caller on a single stream keeps 2.  (r04, profiles/r04_d_c5_plan.md)
+        const bool dense_in_flight = density >= kDenseScene && !q.view_dense && q.in_flight;
         // One dispatch round: up to 1080p (and for the row slabs of a sharded frame) take the smallest count that lets
         // every workgroup be resident at once -- fewer, larger workgroups would leave CUs short of waves (a 135-row
         // slab: 14.0 us with 4 sub-tiles, 9.5 with 1; 270 rows: 17.1 -> 11.9 with 2), more would need a second round;
@@ -227,6 +234,7 @@ inline TileShape plan_tiles(const TileRequest& q)
             const uint64_t one_round = (t.tiles256 + slots - 1) / slots;
             if (one_round <= 6) nsub = (int)(one_round ? one_round : 1);
         }
+        if (dense_in_flight) nsub = 4;
     } else {
         nsub = 1;
         while (nsub < 8 && t.tiles256 >= (uint64_t)nsub * 4000u) nsub *= 2; // keep about 2000 workgroups or more

@@ -1309,9 +1309,22 @@ def main(argv=None):
     if not args.dry and not args.no_native_leg:
         # the same sharded frame behind the C ABI: ONE process (this one) drives all N GPUs through a device group, now that
         # the other ranks have let go of theirs.  A sub-record beside the torch.distributed line, never the line's value.
+        # In a child process with a time limit: the RCCL form of the gather between distinct GPUs has only ever run at one device
+        # on the boxes this was built on, and a sub-record must lose neither the line nor the driver's patience.
         try:
             devs = list(range(n_gpus)) if torch.cuda.device_count() >= n_gpus else [0] * n_gpus
-            out["native_group"] = run_native(args, torch, R, devs, args.config, K, Wm, min(args.prewarm_ms, 50.0))
+            cmd = [sys.executable, os.path.abspath(__file__), "--native", "--gpus", str(n_gpus), "--native-devices", ",".join(str(d) for d in devs),
+                   "--config", args.config, "--mode", args.mode, "--steps", str(K), "--warmup", str(Wm), "--prewarm-ms", str(min(args.prewarm_ms, 50.0)),
+                   "--no-cpu-baseline", "--min-timed-ms", str(args.min_timed_ms)] + (["--no-verify"] if args.no_verify else [])
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240, env=env)
+            line = next((ln for ln in proc.stdout.splitlines()[::-1] if ln.strip().startswith("{")), None)
+            if proc.returncode == 0 and line:
+                rec = json.loads(line)
+                rec.pop("metric", None)
+                out["native_group"] = rec
+            else:
+                out["native_group"] = {"error": "exit code %d: %s" % (proc.returncode, (proc.stderr or "").strip()[-400:])}
         except Exception as exc:   # (a sub-record must not lose the line)
             sys.stderr.write("bench.py: native_group leg failed: %r\n" % (exc,))
             out["native_group"] = {"error": repr(exc)}

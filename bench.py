@@ -214,6 +214,7 @@ def parse_args(argv=None):
     ap.add_argument("--native-frames", type=int, default=8,
                     help="--native: frames per rtx_submit_frames call (every rank traces its rows of that many frames with one batched launch, "
                          "the slabs travel together); 1 = rtx_render, a frame per call")
+    ap.add_argument("--native-threads", type=int, default=-1, help="--native: RTX_OPT_GROUP_THREADS (-1 auto: a submission thread per rank, 0 off)")
     ap.add_argument("--native-wire", default="compact", choices=["compact", "records"], help="--native: what the slabs travel as")
     ap.add_argument("--no-native-leg", action="store_true", help="N>1: skip the native_group sub-record rank 0 measures after the ranks are done")
     ap.add_argument("--dry", action="store_true",
@@ -745,6 +746,8 @@ def run_native(args, torch, R, devices, config, K, Wm, prewarm_ms, update_leg=Tr
         ctx.set_scene(sph, pl)
         apply_options(R, ctx, args)
         ctx.set_option(R.OPT_GROUP_WIRE, R.WIRE_RECORDS if args.native_wire == "records" else R.WIRE_COMPACT)
+        if n > 1:
+            ctx.set_option(R.OPT_GROUP_THREADS, args.native_threads)
         ctx.render(params, mode)
         ctx.synchronize()
         M = max(1, min(args.native_frames, 16, K))

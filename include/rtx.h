@@ -128,6 +128,10 @@ enum rtx_option {
                                * is then not written by an Update (it keeps what the last rtx_render left).  -1 auto (on), 0 off (records:
                                * the frame buffer holds the frame after every Update, as the reference's m_deviceResultArray does), 1 on */
     RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */
+    RTX_OPT_GROUP_THREADS = 16, /* device groups: a submission thread per rank other than the root queues that rank's launch and copy while the
+                               * caller's thread queues the root's (a rank's share is ~15 us of host work; on one thread 8 ranks cost 132 us per
+                               * 1080p frame).  The call still returns only when everything is queued.  -1 auto (on where the list names two or
+                               * more distinct devices; with all ranks on one GPU the threads were measured to change nothing), 0 off, 1 on */
     RTX_OPT_GROUP_WIRE = 13,  /* device groups: enum rtx_group_wire -- what travels: compact pixel words (default) or records */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it

@@ -26,7 +26,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_INVALID_MODE, ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NO_D
 KERNEL_AUTO, KERNEL_BRUTE, KERNEL_BINNED = 0, 1, 2
 OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_ORDER, OPT_CELL_CAPACITY, OPT_CELL_REUSE, OPT_XCD_ORDER, OPT_VIEW_ADAPT, OPT_SORTED_STORE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN, STAT_CELL_CAPACITY_FLOOR, STAT_VIEW_DENSE, STAT_DENSITY_SWITCHES = 101, 102, 103, 104, 105, 106, 107, 108, 109
-OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS = 12, 13, 14, 15
+OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS, OPT_GROUP_THREADS = 12, 13, 14, 15, 16
 STAT_BATCHED_LAUNCHES = 114
 STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, EXCHANGE_RCCL_ALL = 0, 1, 2, 3

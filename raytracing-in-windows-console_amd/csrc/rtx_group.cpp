@@ -24,10 +24,15 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -80,6 +85,19 @@ RcclApi* rccl_api(std::string* why)
 
 } // namespace
 
+// One submission thread per rank other than the root: a rank's share of a frame is a launch, a copy and two events -- about 15 us
+// of host work -- and on the caller's one thread N ranks cost N times that per frame (8 ranks: 132 us per C2 frame on the one-GPU
+// box, where the GPU work is 42).  The caller posts every rank its job, queues the root's own launch meanwhile, and waits for the
+// SUBMISSIONS (not the GPU work) before it orders the root's stream after the ranks' events.
+struct RankWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, busy = false, quit = false;
+    int rc = RTX_OK;
+};
+
 struct rtx_group {
     int n = 0;
     std::vector<rtx_ctx*> member; // [0] = the root (owned by the caller)
@@ -98,6 +116,8 @@ struct rtx_group {
     std::string rccl_error;
     int exchange_in_use = RTX_EXCHANGE_PEER_COPY;
     uint64_t stat_gathers = 0, stat_last_bytes = 0;
+    std::vector<std::unique_ptr<RankWorker>> workers; // [r] for r >= 1 (empty: jobs run on the caller's thread)
+    int64_t opt_threads = -1;                          // -1 auto (on with two or more distinct devices), 0 off, 1 on
 };
 
 namespace {
@@ -107,6 +127,95 @@ int member_fail(rtx_ctx* root, int rank, rtx_ctx* m, int rc)
     char head[48];
     std::snprintf(head, sizeof head, "group rank %d: ", rank);
     return rtx_fail(root, rc, std::string(head) + (m ? m->error : std::string("?")));
+}
+
+void worker_main(RankWorker* w, int device)
+{
+    hipSetDevice(device);
+    std::unique_lock<std::mutex> lock(w->m);
+    for (;;) {
+        w->cv.wait(lock, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        w->has_job = false;
+        std::function<int()> job;
+        job.swap(w->job);
+        lock.unlock();
+        const int rc = job();
+        lock.lock();
+        w->rc = rc;
+        w->busy = false;
+        w->cv.notify_all();
+    }
+}
+
+bool threads_in_use(rtx_group* g)
+{
+    // auto: where the list names at least two DISTINCT devices -- there the ranks' GPU work overlaps and the caller's thread is what
+    // is left in the way.  With every rank on one GPU (the one-GPU box's walk) the GPU serialises the ranks anyway and the threads were
+    // measured to change nothing (8 ranks, a frame per call: 114 us with, 120 without; 8 frames per call: 39.1 / 39.4): off.
+    if (g->opt_threads == 0 || g->n < 2) return false;
+    if (g->opt_threads < 0) {
+        bool two = false;
+        for (int r = 1; r < g->n; r++) two = two || g->device[(size_t)r] != g->device[0];
+        if (!two) return false;
+    }
+    if (g->workers.empty()) {
+        g->workers.resize((size_t)g->n);
+        for (int r = 1; r < g->n; r++) {
+            g->workers[(size_t)r].reset(new RankWorker());
+            g->workers[(size_t)r]->th = std::thread(worker_main, g->workers[(size_t)r].get(), g->device[(size_t)r]);
+        }
+    }
+    return true;
+}
+
+// Rank r's job: on its submission thread, or here and now.
+void post(rtx_group* g, int r, std::function<int()> fn, bool threaded, std::vector<int>& rcs)
+{
+    if (!threaded) {
+        rcs[(size_t)r] = fn();
+        return;
+    }
+    RankWorker* w = g->workers[(size_t)r].get();
+    std::lock_guard<std::mutex> lock(w->m);
+    w->job = std::move(fn);
+    w->has_job = true;
+    w->busy = true;
+    w->rc = RTX_OK;
+    w->cv.notify_all();
+}
+
+// Every posted job has been SUBMITTED (its launches and copies are queued); the first failure, if any, by rank.
+int wait_posted(rtx_ctx* root, rtx_group* g, bool threaded, std::vector<int>& rcs)
+{
+    int first_rc = RTX_OK, first_r = 0;
+    for (int r = 1; r < g->n; r++) {
+        if (threaded) {
+            RankWorker* w = g->workers[(size_t)r].get();
+            std::unique_lock<std::mutex> lock(w->m);
+            w->cv.wait(lock, [&] { return !w->busy; });
+            rcs[(size_t)r] = w->rc;
+        }
+        if (rcs[(size_t)r] != RTX_OK && first_rc == RTX_OK) {
+            first_rc = rcs[(size_t)r];
+            first_r = r;
+        }
+    }
+    return first_rc == RTX_OK ? RTX_OK : member_fail(root, first_r, g->member[(size_t)first_r], first_rc);
+}
+
+void stop_workers(rtx_group* g)
+{
+    for (auto& w : g->workers) {
+        if (!w) continue;
+        {
+            std::lock_guard<std::mutex> lock(w->m);
+            w->quit = true;
+            w->cv.notify_all();
+        }
+        if (w->th.joinable()) w->th.join();
+    }
+    g->workers.clear();
 }
 
 // rows of rank r for a frame of H rows: the partition SURVEY.md 8(e) names (and sharding.row_bounds uses)
@@ -159,44 +268,81 @@ int gather_frame(rtx_ctx* root, rtx_group* g, const rtx_params* p, int mode, boo
     g->exchange_in_use = use_rccl ? RTX_EXCHANGE_RCCL : RTX_EXCHANGE_PEER_COPY;
     int rc;
 
-    // ---- every rank traces its rows
+    if (root_through_rccl) {
+        // (before any job is posted: nothing below this point returns while a rank's submission thread is at work)
+        const size_t need = (size_t)(bound(H, 1, n) * W * S);
+        if (g->root_slab_cap < need) {
+            RTX_HIP(root, hipSetDevice(root->device));
+            if (g->d_root_slab) {
+                RTX_HIP(root, hipStreamSynchronize(root->stream));
+                hipFree(g->d_root_slab);
+            }
+            g->d_root_slab = nullptr;
+            g->root_slab_cap = 0;
+            if (hipMalloc((void**)&g->d_root_slab, need) != hipSuccess) return rtx_fail(root, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for the root's slab");
+            g->root_slab_cap = need;
+        }
+    }
+    // ---- every rank traces its rows (and, with peer copies, sends them): a job per rank, on its submission thread
+    const bool threaded = threads_in_use(g);
+    std::vector<int> rcs((size_t)n, RTX_OK);
+    for (int r = 1; r < n; r++) {
+        const uint64_t rows = bound(H, r + 1, n) - bound(H, r, n);
+        if (rows * W * S > g->member[(size_t)r]->capacity) return rtx_fail(root, RTX_ERR_TOO_LARGE, "frame larger than the group was created for");
+    }
+    if (!use_rccl) {
+        // the destination may still be read by what the root queued before this frame (the previous frame's expansion or
+        // minimise pass): the ranks' copies wait for that, their traces do not have to
+        RTX_HIP(root, hipSetDevice(root->device));
+        RTX_HIP(root, hipEventRecord(g->ev_free, root->stream));
+    }
+    uint64_t moved = 0;
     for (int r = 1; r < n; r++) {
         const uint64_t r0 = bound(H, r, n), rows = bound(H, r + 1, n) - r0;
         if (rows == 0) continue;
         rtx_ctx* m = g->member[(size_t)r];
-        if (rows * W * S > m->capacity) return rtx_fail(root, RTX_ERR_TOO_LARGE, "frame larger than the group was created for");
-        // the member's own frame buffer is its slab: rows [r0, r0 + rows) at its start
-        if ((rc = rtx_render_rows(m, p, mode, (size_t)r0, (size_t)rows, m->d_frame, (size_t)r0, m->stream, slab_flags)) != RTX_OK) return member_fail(root, r, m, rc);
-        m->dirty_hi = m->capacity; // (the buffer is used as scratch: whatever a later plain render on this member assumes about it is void)
+        const size_t bytes = (size_t)(rows * W * S);
+        moved += bytes;
+        const rtx_params pp = *p;
+        uint8_t* dst = d_dst + r0 * W * S;
+        hipEvent_t ev_free = g->ev_free, ev_done = g->ev_done[(size_t)r];
+        const int root_device = root->device;
+        post(g, r, [=]() -> int {
+            // the member's own frame buffer is its slab: rows [r0, r0 + rows) at its start
+            const int rc2 = rtx_render_rows(m, &pp, mode, (size_t)r0, (size_t)rows, m->d_frame, (size_t)r0, m->stream, slab_flags);
+            if (rc2 != RTX_OK) return rc2;
+            m->dirty_hi = m->capacity; // (the buffer is used as scratch: whatever a later plain render on this member assumes about it is void)
+            if (!use_rccl) {
+                RTX_HIP(m, hipSetDevice(m->device));
+                RTX_HIP(m, hipStreamWaitEvent(m->stream, ev_free, 0));
+                RTX_HIP(m, hipMemcpyPeerAsync(dst, root_device, m->d_frame, m->device, bytes, m->stream));
+                RTX_HIP(m, hipEventRecord(ev_done, m->stream));
+            }
+            return RTX_OK;
+        }, threaded, rcs);
     }
     {
         const uint64_t rows0 = bound(H, 1, n);
         if (root_through_rccl) {
             // test form (one-GPU box: RCCL at N = 1): the root's rows too are traced into a slab and travel through the exchange
-            const size_t need = (size_t)(rows0 * W * S);
-            if (g->root_slab_cap < need) {
-                RTX_HIP(root, hipSetDevice(root->device));
-                if (g->d_root_slab) {
-                    RTX_HIP(root, hipStreamSynchronize(root->stream));
-                    hipFree(g->d_root_slab);
-                }
-                g->d_root_slab = nullptr;
-                g->root_slab_cap = 0;
-                if (hipMalloc((void**)&g->d_root_slab, need) != hipSuccess) return rtx_fail(root, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for the root's slab");
-                g->root_slab_cap = need;
-            }
-            if (rows0 && (rc = rtx_render_rows(root, p, mode, 0, (size_t)rows0, g->d_root_slab, 0, root->stream, slab_flags)) != RTX_OK) return rc;
-            if (own_frame && (rc = rtx_frame_zero_semantics(root, mode, W, H, 0u)) != RTX_OK) return rc;
+            rc = rows0 ? rtx_render_rows(root, p, mode, 0, (size_t)rows0, g->d_root_slab, 0, root->stream, slab_flags) : RTX_OK;
+            if (rc == RTX_OK && own_frame) rc = rtx_frame_zero_semantics(root, mode, W, H, 0u);
         } else if (own_frame) {
-            if ((rc = rtx_render_rows(root, p, mode, 0, (size_t)rows0, nullptr, 0, root->stream, RTX_RENDER_DEFAULT)) != RTX_OK) return rc;
+            rc = rtx_render_rows(root, p, mode, 0, (size_t)rows0, nullptr, 0, root->stream, RTX_RENDER_DEFAULT);
         } else {
-            if ((rc = rtx_render_rows(root, p, mode, 0, (size_t)rows0, d_dst, 0, root->stream, root_flags | slab_flags)) != RTX_OK) return rc;
+            rc = rtx_render_rows(root, p, mode, 0, (size_t)rows0, d_dst, 0, root->stream, root_flags | slab_flags);
         }
+    }
+    {
+        // (the ranks' submissions are waited for whatever the root's own launch returned: their jobs hold pointers into this frame)
+        const int wrc = wait_posted(root, g, threaded, rcs);
+        if (rc != RTX_OK) return rc;
+        if (wrc != RTX_OK) return wrc;
     }
 
     // ---- the slabs travel to the root
-    uint64_t moved = 0;
     if (use_rccl) {
+        moved = 0;
         RcclApi* api = rccl_api(nullptr);
         ncclResult_t nrc = api->GroupStart();
         for (int r = root_through_rccl ? 0 : 1; r < n && nrc == ncclSuccess; r++) {
@@ -216,21 +362,7 @@ int gather_frame(rtx_ctx* root, rtx_group* g, const rtx_params* p, int mode, boo
         }
         RTX_HIP(root, hipSetDevice(root->device));
     } else {
-        // the destination may still be read by what the root queued before this frame (the previous frame's expansion or
-        // minimise pass): the copies wait for that, the traces above did not have to
-        RTX_HIP(root, hipSetDevice(root->device));
-        RTX_HIP(root, hipEventRecord(g->ev_free, root->stream));
-        for (int r = 1; r < n; r++) {
-            const uint64_t r0 = bound(H, r, n), rows = bound(H, r + 1, n) - r0;
-            if (rows == 0) continue;
-            rtx_ctx* m = g->member[(size_t)r];
-            const size_t bytes = (size_t)(rows * W * S);
-            RTX_HIP(root, hipSetDevice(m->device));
-            RTX_HIP(root, hipStreamWaitEvent(m->stream, g->ev_free, 0));
-            RTX_HIP(root, hipMemcpyPeerAsync(d_dst + r0 * W * S, root->device, m->d_frame, m->device, bytes, m->stream));
-            RTX_HIP(root, hipEventRecord(g->ev_done[(size_t)r], m->stream));
-            moved += bytes;
-        }
+        // (the copies were queued by the ranks' jobs, behind ev_free; the root's stream goes on when they have landed)
         RTX_HIP(root, hipSetDevice(root->device));
         for (int r = 1; r < n; r++) {
             if (bound(H, r + 1, n) - bound(H, r, n) == 0) continue;
@@ -276,6 +408,7 @@ namespace rtxgroup {
 void destroy(rtx_group* g)
 {
     if (!g) return;
+    stop_workers(g);
     if (!g->comms.empty()) {
         RcclApi* api = rccl_api(nullptr);
         for (size_t r = 0; r < g->comms.size(); r++) {
@@ -351,6 +484,12 @@ int set_option(rtx_ctx* root, int option, int64_t value)
         }
         g->opt_exchange = value;
         if (value != RTX_EXCHANGE_PEER_COPY) g->rccl_failed = false; // asked for again: try again
+        return RTX_OK;
+    }
+    if (option == RTX_OPT_GROUP_THREADS) {
+        if (value < -1 || value > 1) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "RTX_OPT_GROUP_THREADS: -1 (auto), 0 or 1");
+        g->opt_threads = value;
+        if (value == 0) stop_workers(g);
         return RTX_OK;
     }
     if (option == RTX_OPT_GROUP_WIRE) {
@@ -449,18 +588,51 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
             if (compact && (rc = ensure_words(root, g, W, H * m)) != RTX_OK) return rc;
             // where frame i of the chunk is assembled: its words in the group's buffer, or its records in the caller's
             auto dest = [&](size_t i) { return compact ? (uint8_t*)(g->d_words + i * W * H) : (uint8_t*)d_outs[first + i]; };
+            const bool threaded = threads_in_use(g);
+            std::vector<int> rcs((size_t)N, RTX_OK);
+            if (!use_rccl) {
+                RTX_HIP(root, hipSetDevice(root->device));
+                RTX_HIP(root, hipEventRecord(g->ev_free, root->stream));
+            }
+            uint64_t moved = 0;
+            const rtx_params* pfirst = &params[first];
+            uint8_t* dest0 = dest(0);
             for (int r = 1; r < N; r++) {
                 const uint64_t r0 = bound(H, r, N), rows = bound(H, r + 1, N) - r0;
                 if (rows == 0) continue;
                 rtx_ctx* mem = g->member[(size_t)r];
-                for (size_t i = 0; i < m; i++) {
-                    ptrs[i] = mem->d_frame + i * rows * W * S;
-                    strs[i] = mem->stream;
-                }
-                if ((rc = rtx_submit_slabs(mem, m, &params[first], mode, (size_t)r0, (size_t)rows, ptrs.data(), (size_t)r0, strs.data(), nullptr, slab_flags)) != RTX_OK) {
-                    return member_fail(root, r, mem, rc);
-                }
-                mem->dirty_hi = mem->capacity;
+                const size_t bytes = (size_t)(rows * W * S);
+                moved += bytes * m;
+                hipEvent_t ev_free = g->ev_free, ev_done = g->ev_done[(size_t)r];
+                const int root_device = root->device;
+                const bool strided = compact && m > 1 && g->direct[(size_t)r];
+                std::vector<uint8_t*> dests(m);
+                for (size_t i = 0; i < m; i++) dests[i] = dest(i) + r0 * W * S;
+                post(g, r, [=]() -> int {
+                    // the rank's rows of the chunk's frames back to back in its buffer: ONE call, one batched launch where the plan allows
+                    std::vector<void*> p2(m), s2(m);
+                    for (size_t i = 0; i < m; i++) {
+                        p2[i] = mem->d_frame + i * bytes;
+                        s2[i] = mem->stream;
+                    }
+                    const int rc2 = rtx_submit_slabs(mem, m, pfirst, mode, (size_t)r0, (size_t)rows, p2.data(), (size_t)r0, s2.data(), nullptr, slab_flags);
+                    if (rc2 != RTX_OK) return rc2;
+                    mem->dirty_hi = mem->capacity;
+                    if (!use_rccl) {
+                        RTX_HIP(mem, hipSetDevice(mem->device));
+                        RTX_HIP(mem, hipStreamWaitEvent(mem->stream, ev_free, 0));
+                        if (strided) {
+                            // the chunk's slabs lie back to back here and H*W words apart on the root: one strided copy
+                            RTX_HIP(mem, hipMemcpy2DAsync(dest0 + r0 * W * S, (size_t)(H * W * S), mem->d_frame, bytes, bytes, m, hipMemcpyDeviceToDevice, mem->stream));
+                        } else {
+                            for (size_t i = 0; i < m; i++) {
+                                RTX_HIP(mem, hipMemcpyPeerAsync(dests[i], root_device, mem->d_frame + i * bytes, mem->device, bytes, mem->stream));
+                            }
+                        }
+                        RTX_HIP(mem, hipEventRecord(ev_done, mem->stream));
+                    }
+                    return RTX_OK;
+                }, threaded, rcs);
             }
             {
                 const uint64_t rows0 = bound(H, 1, N);
@@ -468,10 +640,15 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
                     ptrs[i] = dest(i);
                     strs[i] = root->stream;
                 }
-                if (rows0 && (rc = rtx_submit_slabs(root, m, &params[first], mode, 0, (size_t)rows0, ptrs.data(), 0, strs.data(), nullptr, slab_flags)) != RTX_OK) return rc;
+                rc = rows0 ? rtx_submit_slabs(root, m, &params[first], mode, 0, (size_t)rows0, ptrs.data(), 0, strs.data(), nullptr, slab_flags) : RTX_OK;
             }
-            uint64_t moved = 0;
+            {
+                const int wrc = wait_posted(root, g, threaded, rcs);
+                if (rc != RTX_OK) return rc;
+                if (wrc != RTX_OK) return wrc;
+            }
             if (use_rccl) {
+                moved = 0;
                 RcclApi* api = rccl_api(nullptr);
                 ncclResult_t nrc = api->GroupStart();
                 for (int r = 1; r < N && nrc == ncclSuccess; r++) {
@@ -490,26 +667,6 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
                 if (nrc != ncclSuccess) return rtx_fail(root, RTX_ERR_HIP, std::string("RCCL exchange failed: ") + (api->GetErrorString ? api->GetErrorString(nrc) : "?"));
                 RTX_HIP(root, hipSetDevice(root->device));
             } else {
-                RTX_HIP(root, hipSetDevice(root->device));
-                RTX_HIP(root, hipEventRecord(g->ev_free, root->stream));
-                for (int r = 1; r < N; r++) {
-                    const uint64_t r0 = bound(H, r, N), rows = bound(H, r + 1, N) - r0;
-                    if (rows == 0) continue;
-                    rtx_ctx* mem = g->member[(size_t)r];
-                    const size_t bytes = (size_t)(rows * W * S);
-                    RTX_HIP(root, hipSetDevice(mem->device));
-                    RTX_HIP(root, hipStreamWaitEvent(mem->stream, g->ev_free, 0));
-                    if (compact && m > 1 && g->direct[(size_t)r]) {
-                        // the chunk's slabs lie back to back in the rank's buffer and H*W words apart on the root: one strided copy
-                        RTX_HIP(root, hipMemcpy2DAsync(dest(0) + r0 * W * S, (size_t)(H * W * S), mem->d_frame, bytes, bytes, m, hipMemcpyDeviceToDevice, mem->stream));
-                    } else {
-                        for (size_t i = 0; i < m; i++) {
-                            RTX_HIP(root, hipMemcpyPeerAsync(dest(i) + r0 * W * S, root->device, mem->d_frame + i * bytes, mem->device, bytes, mem->stream));
-                        }
-                    }
-                    RTX_HIP(root, hipEventRecord(g->ev_done[(size_t)r], mem->stream));
-                    moved += bytes * m;
-                }
                 RTX_HIP(root, hipSetDevice(root->device));
                 for (int r = 1; r < N; r++) {
                     if (bound(H, r + 1, N) - bound(H, r, N) == 0) continue;
@@ -666,6 +823,7 @@ bool rtx_group_stat(const rtx_ctx* ctx, int option, int64_t* value)
     case RTX_STAT_GROUP_BYTES: *value = g ? (int64_t)g->stat_last_bytes : 0; return true;
     case RTX_OPT_GROUP_EXCHANGE: *value = g ? g->opt_exchange : 0; return true;
     case RTX_OPT_GROUP_WIRE: *value = g ? g->opt_wire : 0; return true;
+    case RTX_OPT_GROUP_THREADS: *value = g ? g->opt_threads : 0; return true;
     default: return false;
     }
 }

@@ -165,6 +165,31 @@ def test_rccl_exchange_at_one_device_and_the_fallbacks(R):
             c.set_option(R.OPT_GROUP_WIRE, R.WIRE_RECORDS)
 
 
+def test_submission_threads_on_and_off_render_the_same_frames(R):
+    """RTX_OPT_GROUP_THREADS: a rank's launch and copy are queued by a thread of its own (1; the default where the list names
+    distinct devices) or by the caller's (0; the default on this one-GPU box); the frames, the minimised stream and the error
+    reporting are the same."""
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0] * 6) as c:
+        c.set_scene(sph, pl)
+        assert c.get_option(R.OPT_GROUP_THREADS) == -1
+        for threads in (-1, 0, 1, 0, -1):
+            c.set_option(R.OPT_GROUP_THREADS, threads)
+            for wire in (R.WIRE_COMPACT, R.WIRE_RECORDS):
+                c.set_option(R.OPT_GROUP_WIRE, wire)
+                for _ in range(3):
+                    got = c.render_to_host(p, R.RGB_ASCII)
+                assert _sha(got) == gold["C2_RGB_ASCII"]["frame_sha256"], (threads, wire)
+            st = c.update(p, R.RGB_ASCII)
+            assert len(st) == gold["C2_RGB_ASCII"]["minimized_bytes"] and O.fnv1a64(st) == gold["C2_RGB_ASCII"]["minimized_fnv1a64"], threads
+        with pytest.raises(R.RtxError) as e:
+            c.render(R.camera_params(W, H + 1), R.RGB_ASCII)
+        assert e.value.status == R.ERR_TOO_LARGE
+        assert _sha(c.render_to_host(p, R.RGB_ASCII)) == gold["C2_RGB_ASCII"]["frame_sha256"]   # and the group goes on working
+
+
 def test_options_reach_every_rank_and_errors_name_the_rank(R):
     p, sph, pl = R.config_inputs("C2")
     W, H = int(p.x), int(p.y)

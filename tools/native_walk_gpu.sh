@@ -6,7 +6,10 @@
 CFG=${1:-C2}; STEPS=${2:-192}
 for d in 0 0,0 0,0,0,0 0,0,0,0,0,0,0,0; do
   for m in 1 8 16; do
-    python bench.py --native --config $CFG --native-devices $d --native-frames $m --no-cpu-baseline --steps $STEPS --warmup 32 2>/dev/null | python -c "
+   for t in 1 0; do
+    [ "$t" = 0 ] && [ "$m" = 16 ] && continue
+    printf "threads %s  " $t
+    python bench.py --native --config $CFG --native-devices $d --native-frames $m --native-threads $t --no-cpu-baseline --steps $STEPS --warmup 32 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 e=d.get('end_to_end') or {}
@@ -14,5 +17,6 @@ print('ranks %d  frames/call %2d  %7.2f us/frame (events)  %7.2f us/frame (wall)
     d['logical_ranks'], d['config']['frames_per_call'], d['ms_per_step']*1e3, d['timing']['wall_ms_per_step_median']*1e3,
     d['verified_against_golden'], d['gather_bytes_per_frame'], e.get('ms_per_update_blocking', float('nan')), d['config']['parallelism'].split('exchange: ')[1][:40]))
 "
+   done
   done
 done

@@ -81,6 +81,12 @@ def test_ragged_and_empty_slabs_against_the_oracle(R, ranks, W, H):
                 got = c.render_to_host(p, mode)
                 assert np.array_equal(got, want), (R.MODE_NAMES[mode], wire, U.first_diff(got, want, 20 if mode >= 2 else 12, W))
                 assert np.array_equal(c.update(p, mode), O.minimize(mode, want, W, H)), (R.MODE_NAMES[mode], wire)
+        # the record form of Update over the group (RTX_OPT_UPDATE_WORDS = 0): the gathered frame is minimised, not the words
+        c.set_option(R.OPT_UPDATE_WORDS, 0)
+        for mode in (R.RGB_ASCII, R.BIT_PIXEL):
+            want = O.render(U.oracle_params(p), sc, mode)
+            assert np.array_equal(c.update(p, mode), O.minimize(mode, want, W, H)), R.MODE_NAMES[mode]
+            assert np.array_equal(c.read_frame(20 * W * H), want)
 
 
 def test_update_through_the_group_is_the_single_device_stream(R):

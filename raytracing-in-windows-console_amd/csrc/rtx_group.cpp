@@ -559,6 +559,20 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
         if ((rc = validate_frame(root, &params[i], mode)) != RTX_OK) return rc;
         if (!d_outs[i] || ((uintptr_t)d_outs[i] & 3u) != 0) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "rtx_submit_frames: null or misaligned frame buffer");
     }
+    // the frames are traced and assembled on the root's own stream: first order it after whatever the caller's streams hold for
+    // these buffers (on one device rtx_submit_frames queues frame i ON streams[i]; here the streams are made to wait at the end)
+    if (streams) {
+        RTX_HIP(root, hipSetDevice(root->device));
+        for (size_t i = 0; i < n; i++) {
+            hipStream_t sc = (hipStream_t)streams[i];
+            if (!sc || sc == root->stream) continue;
+            bool seen = false;
+            for (size_t k = 0; k < i; k++) seen = seen || streams[k] == streams[i];
+            if (seen) continue;
+            RTX_HIP(root, hipEventRecord(g->ev_done[0], sc));
+            RTX_HIP(root, hipStreamWaitEvent(root->stream, g->ev_done[0], 0));
+        }
+    }
     bool uniform = mode != RTX_SDL && N > 1;
     for (size_t i = 1; i < n && uniform; i++) {
         uniform = params[i].x == params[0].x && params[i].y == params[0].y;

@@ -56,6 +56,20 @@ static void test_tile_shapes()
     // config 5: dense -> 2 sub-tiles, per-wave refinement, macro tile within 64 x 64
     t = plan_tiles(request(1920, 1080, 1080, 65536, true));
     CHECK(t.nsub == 2 && t.refine && t.mw <= 64 && t.mh <= 64);
+    {
+        // ... with frames in flight on several streams: 4 sub-tiles (the set-up shared by twice the pixels), still refined, still
+        // within the REFINE kernels' 64 x 64 tables; a view that is only locally dense keeps 2
+        TileRequest q = request(1920, 1080, 1080, 65536, true);
+        q.in_flight = true;
+        const TileShape f = plan_tiles(q);
+        CHECK(f.nsub == 4 && f.refine && f.mw <= 64 && f.mh <= 64 && f.mw * f.mh == 1024);
+        TileRequest v = request(1920, 1080, 1080, 1025, true);
+        v.in_flight = true;
+        v.view_dense = true;
+        CHECK(plan_tiles(v).nsub == 2 && plan_tiles(v).refine);
+        v.view_dense = false;
+        CHECK(plan_tiles(v).nsub == 5);
+    }
     // config 3 (4K): 8 sub-tiles; sub-tiles at least 8 pixels wide whatever the pixel aspect
     t = plan_tiles(request(3840, 2160, 2160, 4102, true));
     CHECK(t.nsub == 8 && t.lw >= 3 && !t.refine);

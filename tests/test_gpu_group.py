@@ -66,6 +66,26 @@ def test_group_of_eight_renders_config_4_as_8_slabs_of_540_rows(R):
         assert c.get_option(R.STAT_GROUP_BYTES) == 7 * 540 * W * 20
 
 
+def test_submit_frames_on_a_group_at_8k(R):
+    """Two 8K frames (config 4) per call over 8 ranks: the chunk's slabs -- 540 rows x 7680 words, 16.6 MB each -- travel as one
+    strided copy per rank with a 132 MB pitch."""
+    import torch
+    gold = U.load_golden()["C4_RGB_ASCII"]
+    p, sph, pl = R.config_inputs("C4")
+    W, H = int(p.x), int(p.y)
+    bufs = [torch.empty(20 * W * H, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    with R.Context(W, H, devices=[0] * 8) as g:
+        g.set_scene(sph, pl)
+        for b in bufs:
+            b.fill_(0xEE)
+        torch.cuda.synchronize()
+        g.submit_frames([p, p], R.RGB_ASCII, [b.data_ptr() for b in bufs], [None, None])
+        g.synchronize()
+        for b in bufs:
+            assert O.fnv1a64(b.cpu().numpy()) == gold["frame_fnv1a64"]
+        assert g.get_option(R.STAT_GROUP_BYTES) == 7 * 540 * W * 4
+
+
 @pytest.mark.parametrize("ranks,W,H", [(7, 400, 150), (5, 97, 41), (8, 64, 3), (2, 333, 1), (16, 320, 180)])
 def test_ragged_and_empty_slabs_against_the_oracle(R, ranks, W, H):
     """H not a multiple of N (ragged slabs), more ranks than rows (empty slabs), every mode, both wires: the frame and the

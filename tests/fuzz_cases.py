@@ -232,6 +232,49 @@ def paths_case(R, torch, seed, sizes=PATH_SIZES, oracle_rows=0, max_spheres=1200
         c.synchronize()
         if not torch.equal(got[:S * W * H], want[:S * W * H]):
             found.append("seed %d: expanded compact words differ from the frame, %dx%d mode %d segments %r (%s)" % (seed, W, H, mode, bounds, c.last_kernel))
+        # (c) Minimize from the words against Minimize of the records (the two GPU passes; small frames also against the oracle's)
+        m1 = torch.empty(20 * W * H + 16, dtype=torch.uint8, device="cuda")
+        m2 = torch.empty(20 * W * H + 16, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        n1 = c.minimize(mode, W, H, d_in=want.data_ptr(), d_out=m1.data_ptr())
+        n2 = c.minimize_words(mode, W, H, words.data_ptr(), d_out=m2.data_ptr())
+        if stats is not None:
+            stats["comparisons"] = stats.get("comparisons", 0) + 1
+        if n1 != n2 or not torch.equal(m1[:n1], m2[:n2]):
+            found.append("seed %d: Minimize from words (%d bytes) differs from Minimize of the records (%d bytes), %dx%d mode %d" % (seed, n2, n1, W, H, mode))
+        elif W * H <= 400 * 150:
+            ref = O.minimize(mode, want.cpu().numpy(), W, H)
+            if ref.size != n2 or not np.array_equal(ref, m2[:n2].cpu().numpy()):
+                found.append("seed %d: Minimize from words differs from the oracle's Minimize, %dx%d mode %d" % (seed, W, H, mode))
+        del m1, m2
+        # (d) a slab of three frames with three cameras: one call on one stream (the batched kernel where the plan allows) against
+        # a launch per frame
+        if W * H <= 3840 * 2160:
+            cams = []
+            for i in range(3):
+                q = R.Params.from_buffer_copy(p)
+                q.cam_pos[0] = float(q.cam_pos[0]) + 0.37 * i
+                q.inv_v[1] = float(q.inv_v[1]) + 1e-3 * i
+                cams.append(q)
+            r0 = int(g.integers(0, H))
+            rows = int(g.integers(1, H - r0 + 1))
+            nb = rows * W * S
+            a3 = [torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(3)]
+            b3 = [torch.empty(nb, dtype=torch.uint8, device="cuda") for _ in range(3)]
+            for t in a3 + b3:
+                t.fill_(0xEE)
+            torch.cuda.synchronize()
+            c.submit_slabs(cams, mode, r0, rows, [t.data_ptr() for t in a3], r0, [None] * 3)
+            for i in range(3):
+                c.render_rows(cams[i], mode, r0, rows, d_out=b3[i].data_ptr(), out_row_base=r0)
+            c.synchronize()
+            if stats is not None:
+                stats["comparisons"] = stats.get("comparisons", 0) + 1
+                stats["batched"] = c.get_option(R.STAT_BATCHED_LAUNCHES) + stats.get("batched", 0)
+            for i in range(3):
+                if not torch.equal(a3[i], b3[i]):
+                    found.append("seed %d: frame %d of a three-frame slab call (rows %d+%d) differs from its own launch, %dx%d mode %d (%s)" % (seed, i, r0, rows, W, H, mode, c.last_kernel))
+            del a3, b3
         if oracle_rows:
             sc = O.Scene.from_arrays(sph, pl)
             op = U.oracle_params(p)

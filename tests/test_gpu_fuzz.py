@@ -43,7 +43,7 @@ def test_culling_plans_against_the_brute_kernel_and_sampled_rows_against_the_ora
     assert len(stats["kernels"]) >= 2, stats["kernels"]     # more than one culling kernel form was exercised
 
 
-def test_slabs_and_expanded_words_against_the_frame_and_sampled_rows_against_the_oracle(R):
+def test_slabs_expanded_words_minimize_and_batches_against_the_frame_and_the_oracle(R):
     import torch
     stats, found, ran = {}, [], 0
     t_end = time.time() + BUDGET_S
@@ -54,7 +54,8 @@ def test_slabs_and_expanded_words_against_the_frame_and_sampled_rows_against_the
         found += F.paths_case(R, torch, seed, oracle_rows=4, max_spheres=3000, stats=stats)
         ran += 1
     assert not found, "\n".join(found)
-    assert ran >= MIN_CASES and stats["comparisons"] == 2 * ran and stats["oracle_rows"] >= 2 * ran
+    assert ran >= MIN_CASES and stats["comparisons"] >= 3 * ran and stats["oracle_rows"] >= 2 * ran
+    assert stats.get("batched", 0) >= 1      # some of the three-frame slab calls went through the batched kernel
 
 
 def test_moving_camera_over_reused_cell_lists_against_the_oracle(R):

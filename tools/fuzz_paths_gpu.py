@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised check of the paths around the trace kernel against the whole frame rendered in one launch: the same frame as
 row slabs (the unit a sharded run renders: random cuts, every slab its own launch), and as compact pixel words expanded into
-records (what travels between GPUs).  All five character modes.  The long-running front end of tests/fuzz_cases.py
+records (what travels between GPUs), Minimize from the words against Minimize of the records, and a three-frame slab call (the
+batched kernel where the plan allows) against a launch per frame.  All five character modes.  The long-running front end of tests/fuzz_cases.py
 (tests/test_gpu_fuzz.py runs a bounded share inside `pytest -m gpu`).
 
   python tools/fuzz_paths_gpu.py [seconds] [first_seed] [--oracle-rows=N]

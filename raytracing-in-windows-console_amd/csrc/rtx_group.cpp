@@ -103,7 +103,7 @@ struct rtx_group {
     std::vector<rtx_ctx*> member; // [0] = the root (owned by the caller)
     std::vector<int> device;
     bool distinct = true;         // no device appears twice in the list
-    std::vector<char> direct;     // per rank: its device and the root's address each other's memory (same device, or peer access enabled)
+    std::vector<char> direct;     // per rank: its device and the root's address each other's memory (same device, or peer access enabled) and strided copies between them work
     std::vector<hipEvent_t> ev_done; // per rank, on its device: its slab has arrived on the root (peer copies)
     hipEvent_t ev_free = nullptr;    // root's device: the destination may be overwritten
     uint32_t* d_words = nullptr;     // root's device: the frame as compact words (W * H)
@@ -620,6 +620,7 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
                 hipEvent_t ev_free = g->ev_free, ev_done = g->ev_done[(size_t)r];
                 const int root_device = root->device;
                 const bool strided = compact && m > 1 && g->direct[(size_t)r];
+                auto* direct_flag = &g->direct[(size_t)r];
                 std::vector<uint8_t*> dests(m);
                 for (size_t i = 0; i < m; i++) dests[i] = dest(i) + r0 * W * S;
                 post(g, r, [=]() -> int {
@@ -635,10 +636,17 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
                     if (!use_rccl) {
                         RTX_HIP(mem, hipSetDevice(mem->device));
                         RTX_HIP(mem, hipStreamWaitEvent(mem->stream, ev_free, 0));
+                        bool copied = false;
                         if (strided) {
-                            // the chunk's slabs lie back to back here and H*W words apart on the root: one strided copy
-                            RTX_HIP(mem, hipMemcpy2DAsync(dest0 + r0 * W * S, (size_t)(H * W * S), mem->d_frame, bytes, bytes, m, hipMemcpyDeviceToDevice, mem->stream));
-                        } else {
+                            // the chunk's slabs lie back to back here and H*W words apart on the root: one strided copy.  A runtime
+                            // that refuses the strided form between two devices gets the plain copies below, from then on.
+                            copied = hipMemcpy2DAsync(dest0 + r0 * W * S, (size_t)(H * W * S), mem->d_frame, bytes, bytes, m, hipMemcpyDeviceToDevice, mem->stream) == hipSuccess;
+                            if (!copied) {
+                                (void)hipGetLastError();
+                                *direct_flag = 0;
+                            }
+                        }
+                        if (!copied) {
                             for (size_t i = 0; i < m; i++) {
                                 RTX_HIP(mem, hipMemcpyPeerAsync(dests[i], root_device, mem->d_frame + i * bytes, mem->device, bytes, mem->stream));
                             }

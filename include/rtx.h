@@ -127,6 +127,11 @@ enum rtx_option {
                                * memory traffic (1080p RGB: 8.3 MB written + 16.6 MB read instead of 41.5 + 83).  The context's frame buffer
                                * is then not written by an Update (it keeps what the last rtx_render left).  -1 auto (on), 0 off (records:
                                * the frame buffer holds the frame after every Update, as the reference's m_deviceResultArray does), 1 on */
+    RTX_OPT_MINIMIZE_FUSED = 17, /* the word form of Minimize (rtx_minimize_words, rtx_update with RTX_OPT_UPDATE_WORDS) as ONE launch: every block counts
+                               * its slots, publishes its length and finds its place in the stream by a two-level look-back over the lengths of
+                               * the blocks before it, instead of three launches (count, offsets, scatter) that read the words twice.  A launch
+                               * whose blocks gave up waiting (bounded polling; never seen) is redone as three launches: RTX_STAT_MINIMIZE_FALLBACKS.
+                               * -1 auto (on), 0 off, 1 on, 2 on with blocks that give up on purpose (tests of that path) */
     RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */
     RTX_OPT_GROUP_THREADS = 16, /* device groups: a submission thread per rank other than the root queues that rank's launch and copy while the
                                * caller's thread queues the root's (a rank's share is ~15 us of host work; on one thread 8 ranks cost 132 us per
@@ -149,6 +154,7 @@ enum rtx_stat {
     RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
     RTX_STAT_BATCHED_LAUNCHES = 114, /* launches that rendered several frames' slabs at once (RTX_OPT_BATCH) */
+    RTX_STAT_MINIMIZE_FALLBACKS = 115, /* fused Minimize launches redone as three launches (RTX_OPT_MINIMIZE_FUSED) */
     RTX_STAT_GROUP_SIZE = 110,      /* logical ranks of the device group this context is the root of (1: a plain context) */
     RTX_STAT_GROUP_EXCHANGE = 111,  /* the exchange the last sharded frame used: RTX_EXCHANGE_PEER_COPY or RTX_EXCHANGE_RCCL (0: none yet) */
     RTX_STAT_GROUP_GATHERS = 112,   /* sharded frames gathered so far */

@@ -28,6 +28,8 @@ OPT_KERNEL, OPT_TILE_LOG2_W, OPT_SUBTILES, OPT_TWO_LEVEL, OPT_REFINE, OPT_TILE_O
 STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STAT_ORDER_PASSES, STAT_ORDERS_FROZEN, STAT_CELL_CAPACITY_FLOOR, STAT_VIEW_DENSE, STAT_DENSITY_SWITCHES = 101, 102, 103, 104, 105, 106, 107, 108, 109
 OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS, OPT_GROUP_THREADS = 12, 13, 14, 15, 16
 STAT_BATCHED_LAUNCHES = 114
+OPT_MINIMIZE_FUSED = 17
+STAT_MINIMIZE_FALLBACKS = 115
 STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, EXCHANGE_RCCL_ALL = 0, 1, 2, 3
 WIRE_AUTO, WIRE_RECORDS, WIRE_COMPACT = 0, 1, 2

@@ -34,6 +34,12 @@ struct rtx_ctx {
     uint32_t* d_words = nullptr;    // rtx_update's pixel words (W * H; allocated on first use)
     size_t words_cap = 0;
     int64_t opt_update_words = -1;  // -1 auto (on), 0 off: rtx_update traces pixel words and minimises from them
+    uint64_t* d_look = nullptr;     // rtx_minw_fused's look-back tables (agg, grp: rtx_post.hip), zeroed when allocated
+    size_t look_blocks = 0;         // ... sized for this many blocks
+    uint32_t look_epoch = 0;        // of the last fused launch (0: none yet; never used as a tag)
+    uint32_t min_fused_epoch = 0;   // not 0: the minimise launches just queued were the fused kind, under this epoch
+    int64_t opt_min_fused = -1;     // RTX_OPT_MINIMIZE_FUSED: -1 auto (on), 0 three launches, 1 on, 2 on with blocks that give up (tests)
+    uint64_t stat_min_fallbacks = 0; // fused minimise launches that gave up and were redone as three launches
     uint8_t* d_grey = nullptr;
     size_t dirty_hi = 0;            // bytes of d_frame that may be non-zero
 

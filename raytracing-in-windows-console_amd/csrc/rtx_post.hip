@@ -425,34 +425,17 @@ __device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, 
 // thread's by a 32-bit one (a 64-bit division per thread is ~100 instructions, a third of what this pass executes).
 __device__ __forceinline__ uint32_t first_column(uint64_t base, uint32_t W)
 {
-    const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base % W));
+    // (a 64-bit remainder is ~130 instructions, a tenth of what a wave of the one-launch form executes: 32-bit where the slot fits)
+    const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((base >> 32) == 0u ? (uint32_t)base % W : (uint32_t)(base % W));
     return (col0 + threadIdx.x * (uint32_t)kWPerThread) % W; // (col0 < W < 2^31 and the offset < 1024: no overflow)
 }
 
-// Emitted length of slot g (column col, staged at s_w[2 + li]); `w` receives its word.
+// The previous ESC slot of slot g is not among the two staged before it (a frame that was only partly rendered: empty slots in
+// between): walk back through global memory.  Rare, and kept out of line so that the passes' straight-line code stays short.
 template <int MODE>
-__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w)
+__device__ __noinline__ uint32_t word_length_walk(const uint32_t* __restrict__ words, uint64_t g, uint32_t W, uint32_t w)
 {
     constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
-    w = s_w[2 + li];
-    if (col == W - 1u) {
-        return 1u; // newline
-    }
-    if (w == kNoWord) {
-        return 0u; // empty slot
-    }
-    if (g == 0) {
-        return S; // first pixel of the frame
-    }
-    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's last column
-    const int back = col == 0u ? 2 : 1;
-    if (g >= (uint64_t)back) {
-        const uint32_t pw = s_w[2 + li - back];
-        if (pw != kNoWord) {
-            return colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
-        }
-    }
-    // not a fully rendered frame (empty slots in between): walk back through global memory
     uint64_t j = g;
     while (j > 0) {
         --j;
@@ -465,6 +448,27 @@ __device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ wor
         }
     }
     return S;
+}
+
+// Emitted length of slot g (column col, staged at s_w[2 + li]); `w` receives its word.  Selects, and one branch for the rare walk.
+template <int MODE>
+__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w)
+{
+    constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
+    w = s_w[2 + li];
+    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's last column (both staged: s_w[0..1] precede the block)
+    const int back = col == 0u ? 2 : 1;
+    const uint32_t pw = s_w[2 + li - back];
+    const bool newline = col == W - 1u, empty = w == kNoWord, first = g == 0;
+    const bool staged = g >= (uint64_t)back && pw != kNoWord;
+    uint32_t len = colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
+    len = first ? S : len;     // first pixel of the frame
+    len = empty ? 0u : len;    // empty slot
+    len = newline ? 1u : len;
+    if (!newline && !empty && !first && !staged) {
+        len = word_length_walk<MODE>(words, g, W, w);
+    }
+    return len;
 }
 
 template <int MODE>
@@ -602,6 +606,191 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __r
     }
 }
 
+// ---- the same pass as ONE launch (rtx_minw_fused): count, offsets and scatter of the three launches above in one kernel, the
+// block offsets by a two-level look-back.  Three dependent launches of a few microseconds each pay two launch gaps and read the
+// words twice; here a block counts its slots, publishes its length, builds its output bytes in LDS while the other blocks do the
+// same, and then finds where its bytes go:
+//   * agg[b]  = (epoch << 32) | length of block b            published by every block as soon as it has counted
+//   * grp[r][g] = (epoch << 32) | length of blocks 64g..64g+63  published by the LAST block of the group, which reads the other 63
+//     lengths for its own offset anyway; 64 replicas r (rows of `ng` entries), block b reads replica b % 64
+//   * offset of block b = sum of grp[b % 64][0 .. b/64) + sum of agg[64 (b/64) .. b): one wave, one or a few loads per lane, two
+//     dependent steps for every block however many blocks there are (no chain of prefixes from block to block).
+// A block waits only for blocks with smaller indices; workgroups are dispatched in index order on every XCD, so the unfinished
+// block with the smallest index never waits and the launch drains.  All the same nothing here spins without a bound: a lane that
+// has polled max_polls times gives up, the block writes the launch's epoch into the failure word and stores nothing, a group's
+// last block that gave up publishes a poisoned total (the later blocks then give up at once), and the host runs the three
+// launches above instead (launch_minimize_words, settle_minimize_words).  Entries carry the launch's epoch, so the tables are
+// never cleared between launches; they are zeroed when allocated and epoch 0 is never used.
+constexpr uint32_t kLookGroup = 64u;
+constexpr uint32_t kLookPoison = 0xffffffffu;
+constexpr uint32_t kLookPolls = 1u << 18; // x >= 0.5 us per poll: at least a tenth of a second
+
+__device__ __forceinline__ bool look_wait(const uint64_t* p, uint32_t epoch, uint32_t max_polls, uint32_t& value)
+{
+    for (uint32_t i = 0;; i++) {
+        const uint64_t e = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(e >> 32) == epoch) {
+            value = (uint32_t)e;
+            return true;
+        }
+        if (i >= max_polls) {
+            value = 0u;
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng,
+                                                           uint32_t epoch, uint32_t max_polls, uint8_t* out, uint64_t* total_out)
+{
+    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
+    constexpr uint32_t S = kRgb ? 20u : 12u;
+    // the words first (2 + 1024 dwords) and the scan's partial sums behind them, then -- once every thread has its lengths -- the
+    // output bytes from offset 0, at most 1024 x S of them.  (What bounds this launch is the order its dependency imposes on the whole
+    // GPU -- every block reads and counts, then every block waits two memory round trips, then every block writes: per-block
+    // time stamps of a 1080p frame show lengths published at 2-4 us, offsets known at 6-8, the last byte written at 12.7 -- not the
+    // number of resident blocks or of instructions: a build with 20 480 bytes of LDS, eight blocks per CU and all 2025 blocks in
+    // one dispatch round was no faster, nor was halving the instructions of the length pass.  EXPERIMENTS.md R4.5.)
+    __shared__ __attribute__((aligned(16))) uint8_t s_buf[kWSlotsPerBlock * S];
+    __shared__ uint32_t s_digits[256];
+    __shared__ uint64_t s_G;
+    __shared__ uint32_t s_ok;
+    static_assert(sizeof(s_buf) >= (2 + kWSlotsPerBlock) * 4 + 8 + (kThreads / 64) * 4, "words + partial sums fit the image's space");
+    uint32_t* s_w = reinterpret_cast<uint32_t*>(s_buf);
+    uint32_t* s_wave = s_w + 2 + kWSlotsPerBlock + 2;
+    const uint32_t b = blockIdx.x;
+    const uint64_t base = (uint64_t)b * kWSlotsPerBlock;
+    stage_words(words, base, n_slots, s_w);
+    s_digits[threadIdx.x] = digits_word(threadIdx.x);
+    uint32_t col = first_column(base, W);
+    __syncthreads();
+
+    uint32_t len[kWPerThread], wd[kWPerThread], cols[kWPerThread], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kWPerThread; k++) {
+        const int li = (int)threadIdx.x * kWPerThread + k;
+        const uint64_t g = base + (uint64_t)li;
+        len[k] = 0u;
+        wd[k] = kNoWord;
+        cols[k] = col;
+        if (g < n_slots) {
+            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k]);
+        }
+        mine += len[k];
+        col = col + 1u == W ? 0u : col + 1u;
+    }
+    uint32_t n;
+    uint32_t at = block_exclusive_scan(mine, s_wave, n); // (its barriers: every thread has read its words and the sums; s_buf is free)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&agg[b], ((uint64_t)epoch << 32) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
+    // the output bytes, built while the other blocks publish their lengths
+#pragma unroll
+    for (int k = 0; k < kWPerThread; k++) {
+        uint8_t* dst = s_buf + at;
+        if (len[k] == S) {
+            Fields f;
+            f.c0 = wd[k] & 255u;
+            f.c1 = (wd[k] >> 8) & 255u;
+            f.c2 = (wd[k] >> 16) & 255u;
+            f.glyph = wd[k] >> 24;
+            uint32_t r[S / 4];
+            record_words<MODE>(wd[k] != kCompactMiss, f, s_digits, r);
+#pragma unroll
+            for (uint32_t q = 0; q < S / 4u; q++) {
+                *reinterpret_cast<u32_unaligned*>(dst + 4u * q) = r[q];
+            }
+        } else if (len[k] == 1u) {
+            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (wd[k] == kCompactMiss ? (uint8_t)' ' : (uint8_t)(wd[k] >> 24));
+        }
+        at += len[k];
+    }
+
+    // the look-back, by the first wave
+    if (threadIdx.x < 64u) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t g = b / kLookGroup, first = g * kLookGroup;
+        uint64_t before = 0, in_group = 0;
+        bool ok_group = true, ok_before = true;
+        if (first + lane < b) {
+            uint32_t v;
+            ok_group = look_wait(&agg[first + lane], epoch, max_polls, v);
+            in_group = v;
+        }
+        if (max_polls == 0u && b % 3u == 1u) {
+            ok_group = false; // (tests: a launch whose blocks give up, RTX_OPT_MINIMIZE_FUSED = 2)
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            in_group += __shfl_xor(in_group, d);
+        }
+        ok_group = __all(ok_group);
+        if (b % kLookGroup == kLookGroup - 1u) {
+            // the group's total, once per replica (lane r writes replica r: 64 lines) and BEFORE this block looks at the totals
+            // of the groups before it: a total depends on its own group only, so all of them appear at about the same time
+            // (published after that look, they formed a chain, 0.85 us per group: 30 us at 1080p)
+            const uint32_t t = ok_group ? (uint32_t)in_group + n : kLookPoison;
+            __hip_atomic_store(&grp[(size_t)lane * ng + g], ((uint64_t)epoch << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (replica b % 64 of the totals, so that a total's readers are spread over 64 lines)
+        const uint64_t* my_grp = grp + (size_t)(b % kLookGroup) * ng;
+        for (uint32_t q = lane; q < g && ok_before; q += 64u) {
+            uint32_t v;
+            ok_before = look_wait(&my_grp[q], epoch, max_polls, v) && v != kLookPoison;
+            before += v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d);
+        }
+        ok_before = __all(ok_before);
+        if (lane == 0u) {
+            s_G = before + in_group;
+            s_ok = (ok_group && ok_before) ? 1u : 0u;
+        }
+    }
+    __syncthreads(); // the image is complete, the offset known
+    if (s_ok == 0u) {
+        if (threadIdx.x == 0) {
+            total_out[1] = epoch; // the host runs the three-launch form over the same words
+        }
+        return;
+    }
+    const uint64_t G = s_G;
+    // copy out: bytes [G, G + n); the LDS image starts at offset 0 whatever G's phase, so a 16-byte line of the destination is five
+    // aligned dwords of the image and a byte shift (four unaligned dword reads become an unaligned ds_read_b128, which is slow)
+    const uint32_t pad = (uint32_t)(G & 15u);
+    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
+    const uint32_t body16 = (n - head) / 16u;
+    const uint32_t tail = n - head - body16 * 16u;
+    if (threadIdx.x < head) {
+        out[G + threadIdx.x] = s_buf[threadIdx.x];
+    }
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(s_buf) + (head >> 2);
+    const uint32_t shift = head & 3u;
+    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
+    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
+        // (the fifth dword of the image's last line may lie past the image: read only what exists)
+        const uint32_t a0 = src32[4u * i], a1 = src32[4u * i + 1u], a2 = src32[4u * i + 2u], a3 = src32[4u * i + 3u];
+        const uint32_t a4 = shift != 0u ? src32[4u * i + 4u] : 0u;
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(a1, a0, shift);
+        v.y = __builtin_amdgcn_alignbyte(a2, a1, shift);
+        v.z = __builtin_amdgcn_alignbyte(a3, a2, shift);
+        v.w = __builtin_amdgcn_alignbyte(a4, a3, shift);
+        dst16[i] = v;
+    }
+    if (threadIdx.x < tail) {
+        out[G + head + body16 * 16u + threadIdx.x] = s_buf[head + body16 * 16u + threadIdx.x];
+    }
+    if (b == gridDim.x - 1u && threadIdx.x == 0) {
+        total_out[0] = G + n; // length of the minimised stream
+    }
+}
+
 } // namespace rtx
 
 namespace {
@@ -661,8 +850,8 @@ size_t words_scan_bytes(uint64_t n_slots)
     return n_blocks * (sizeof(uint32_t) + sizeof(uint64_t)) + 64;
 }
 
-// Minimize from W*H pixel words (every mode but SDL) on the context's stream; scratch laid out as launch_minimize's.
-int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
+// Minimize from W*H pixel words (every mode but SDL) on the context's stream as three launches; scratch laid out as launch_minimize's.
+int launch_minimize_words_chain(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const unsigned n_blocks = (unsigned)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock);
@@ -687,6 +876,86 @@ int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
 #undef RTX_MINW
     RTX_HIP(ctx, hipGetLastError());
     *d_total = total;
+    return RTX_OK;
+}
+
+// The look-back tables of rtx_minw_fused: agg (one entry per block) then 64 replicas of grp (one entry per 64 blocks); zeroed when allocated, tagged by
+// epoch afterwards.  One set per context: every minimise launch runs on the context's stream, one after the other.
+int ensure_look_tables(rtx_ctx* ctx, size_t n_blocks)
+{
+    if (ctx->look_blocks >= n_blocks && ctx->d_look) return RTX_OK;
+    if (ctx->d_look) {
+        RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->d_look);
+        ctx->d_look = nullptr;
+        ctx->look_blocks = 0;
+    }
+    size_t cap = 4096;
+    while (cap < n_blocks) cap *= 2;
+    const size_t bytes = 2 * cap * sizeof(uint64_t); // agg[cap], then 64 replicas of grp[cap / 64]
+    if (hipMalloc((void**)&ctx->d_look, bytes) != hipSuccess) {
+        ctx->d_look = nullptr;
+        return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for the minimise look-back tables");
+    }
+    RTX_HIP(ctx, hipMemsetAsync(ctx->d_look, 0, bytes, ctx->stream));
+    ctx->look_blocks = cap;
+    return RTX_OK;
+}
+
+// Minimize from W*H pixel words on the context's stream: one launch (rtx_minw_fused, RTX_OPT_MINIMIZE_FUSED) or the three above.
+// (*d_total)[0] will hold the stream's length; after a fused launch (ctx->min_fused_epoch != 0) (*d_total)[1] == that epoch says
+// that blocks gave up: settle_minimize_words then redoes the frame with the three launches.
+int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
+{
+    const uint64_t n_slots = (uint64_t)w * h;
+    const uint64_t n_blocks = (n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock;
+    ctx->min_fused_epoch = 0;
+    if (ctx->opt_min_fused == 0 || n_blocks > (1u << 24)) return launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, d_total);
+    int rc = ensure_look_tables(ctx, (size_t)n_blocks);
+    if (rc != RTX_OK) return rc;
+    if (++ctx->look_epoch == 0u) {
+        // the tags have wrapped: forget every entry
+        RTX_HIP(ctx, hipMemsetAsync(ctx->d_look, 0, 2 * ctx->look_blocks * sizeof(uint64_t), ctx->stream));
+        ctx->look_epoch = 1u;
+    }
+    const uint32_t epoch = ctx->look_epoch;
+    uint64_t* total = (uint64_t*)d_scan;
+    uint64_t* agg = ctx->d_look;
+    uint64_t* grp = agg + ctx->look_blocks;
+    const uint32_t ng = (uint32_t)(ctx->look_blocks / rtx::kLookGroup);
+    const uint32_t polls = ctx->opt_min_fused == 2 ? 0u : rtx::kLookPolls;
+    hipStream_t st = ctx->stream;
+#define RTX_MINF(M) \
+    hipLaunchKernelGGL((rtx::rtx_minw_fused<M>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, agg, grp, ng, epoch, polls, d_out, total)
+    switch (mode) {
+    case RTX_BIT_ASCII: RTX_MINF(RTX_K_BIT_ASCII); break;
+    case RTX_BIT_PIXEL: RTX_MINF(RTX_K_BIT_PIXEL); break;
+    case RTX_RGB_ASCII: RTX_MINF(RTX_K_RGB_ASCII); break;
+    case RTX_RGB_PIXEL: RTX_MINF(RTX_K_RGB_PIXEL); break;
+    case RTX_RGB_NORMALS: RTX_MINF(RTX_K_RGB_NORMALS); break;
+    default: return rtx_fail(ctx, RTX_ERR_INVALID_MODE, "no pixel words in this mode");
+    }
+#undef RTX_MINF
+    RTX_HIP(ctx, hipGetLastError());
+    ctx->min_fused_epoch = epoch;
+    *d_total = total;
+    return RTX_OK;
+}
+
+// got[0], got[1]: the two words at *d_total as the host read them after the launches of launch_minimize_words.  A fused launch
+// whose blocks gave up is redone here as three launches (the stream is synchronised again); *total = the stream's length.
+int settle_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, const uint64_t got[2], uint64_t* total)
+{
+    *total = got[0];
+    const uint32_t epoch = ctx->min_fused_epoch;
+    ctx->min_fused_epoch = 0;
+    if (epoch == 0u || got[1] != (uint64_t)epoch) return RTX_OK;
+    ctx->stat_min_fallbacks++;
+    uint64_t* d_total = nullptr;
+    int rc = launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, &d_total);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemcpyAsync(total, d_total, sizeof *total, hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTX_OK;
 }
 
@@ -820,9 +1089,10 @@ int rtx_minimize_words(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d
     if (!d_out) d_out = ctx->d_min;
     uint64_t* d_total = nullptr;
     if ((rc = launch_minimize_words(ctx, ctx->d_scan, mode, w, h, (const uint32_t*)d_words, (uint8_t*)d_out, &d_total)) != RTX_OK) return rc;
-    uint64_t total = 0;
-    RTX_HIP(ctx, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t got[2] = {0, 0}, total = 0;
+    RTX_HIP(ctx, hipMemcpyAsync(got, d_total, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = settle_minimize_words(ctx, ctx->d_scan, mode, w, h, (const uint32_t*)d_words, (uint8_t*)d_out, got, &total)) != RTX_OK) return rc;
     *out_bytes = (size_t)total;
     return RTX_OK;
 }
@@ -893,7 +1163,7 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
         sl.d_min = nullptr;
         return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipMalloc failed for an update slot's minimise buffer");
     }
-    if (!sl.h_total && hipHostMalloc((void**)&sl.h_total, sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+    if (!sl.h_total && hipHostMalloc((void**)&sl.h_total, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
         sl.h_total = nullptr;
         return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipHostMalloc failed for an update slot");
     }
@@ -912,9 +1182,9 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     int rc;
     if (run_physics && (rc = rtx_update_objects(ctx, dt)) != RTX_OK) return rc;
     uint64_t* d_total = nullptr;
+    const uint32_t* d_words = nullptr;
     if (from_words) {
         // pixel words into the slot's own buffer (a group: into the group's, gathered), minimised from there
-        const uint32_t* d_words = nullptr;
         if ((rc = trace_words(ctx, params, mode, &sl.d_words, &sl.words_cap, &d_words)) != RTX_OK) return rc;
         if ((rc = launch_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, sl.d_min, &d_total)) != RTX_OK) return rc;
     } else {
@@ -931,11 +1201,16 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     }
     if ((rc = launch_minimize(ctx, sl.d_scan, mode, w, h, sl.d_frame, sl.d_min, &d_total)) != RTX_OK) return rc;
     }
-    RTX_HIP(ctx, hipMemcpyAsync(sl.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipMemcpyAsync(sl.h_total, d_total, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipEventRecord(sl.ev_ready, ctx->stream));
     // the length is needed on the host to size the copy: wait for this frame's kernels (the previous frame's
     // copy keeps running on the copy stream meanwhile)
     RTX_HIP(ctx, hipEventSynchronize(sl.ev_ready));
+    if (from_words) {
+        uint64_t total = 0;
+        if ((rc = settle_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, sl.d_min, sl.h_total, &total)) != RTX_OK) return rc;
+        sl.h_total[0] = total;
+    }
     sl.bytes = (size_t)*sl.h_total;
     if (sl.bytes) {
         RTX_HIP(ctx, hipMemcpyAsync(host_out, sl.d_min, sl.bytes, hipMemcpyDeviceToHost, ctx->copy_stream));

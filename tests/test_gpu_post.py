@@ -495,3 +495,94 @@ def test_update_from_words_and_from_records_hand_over_the_same_stream(R):
         # SDL has no words: one newline per row either way
         c.set_option(R.OPT_UPDATE_WORDS, -1)
         assert bytes(c.update(p, R.SDL)) == b"\n" * H
+
+
+# ---- the one-launch form of Minimize from words (rtx_minw_fused, RTX_OPT_MINIMIZE_FUSED)
+
+def _random_words(rng, w, h, runs, holes):
+    """Pixel words of a made-up frame: colours in runs of random length (so that escapes are elided), misses, optional empty slots."""
+    n = w * h
+    colours = rng.integers(0, 1 << 24, size=n, dtype=np.uint32)
+    keep = rng.random(n) < runs
+    idx = np.where(~keep, np.arange(n), 0)
+    np.maximum.accumulate(idx, out=idx)
+    colours = colours[idx]
+    glyph = rng.integers(33, 127, size=n, dtype=np.uint32)
+    words = (glyph << 24) | colours
+    words[rng.random(n) < 0.2] = 0                       # misses
+    if holes:
+        words[rng.random(n) < holes] = 0xFFFFFFFF
+    hw = words.reshape(h, w)
+    hw[:, w - 1] = 0xFFFFFFFF                            # the newline column as the trace kernel leaves it
+    return hw.reshape(-1).astype(np.uint32)
+
+
+@pytest.mark.parametrize("res", [(1024, 1), (1024, 63), (1024, 64), (1024, 65), (1024, 129), (1920, 1080), (3840, 2160), (977, 331), (5, 3)])
+def test_fused_minimize_is_the_three_launch_minimize(R, ctx, res):
+    """One launch with a two-level look-back (64 blocks per group: frames of 1, 63, 64, 65, 129, 2025 and 8100 blocks) against the
+    three launches (RTX_OPT_MINIMIZE_FUSED = 0) on the same words, every mode family, with and without empty slots; the small
+    sizes also against the oracle's Minimize of the expanded records."""
+    import torch
+    w, h = res
+    rng = np.random.default_rng(w * 7919 + h)
+    for mode, holes in ((R.RGB_ASCII, 0.0), (R.BIT_PIXEL, 0.0), (R.RGB_NORMALS, 0.05)):
+        S = 20 if mode >= R.RGB_ASCII else 12
+        hw = _random_words(rng, w, h, runs=0.7, holes=holes)
+        if mode < R.RGB_ASCII:
+            hw = np.where((hw != 0) & (hw != 0xFFFFFFFF), hw & np.uint32(0xFF0000FF), hw).astype(np.uint32)   # an index and a glyph
+        words = torch.from_numpy(hw.view(np.int32)).cuda()
+        out = {}
+        for fused in (0, 1):
+            ctx.set_option(R.OPT_MINIMIZE_FUSED, fused)
+            dst = torch.full((S * w * h + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            n = ctx.minimize_words(mode, w, h, words.data_ptr(), d_out=dst.data_ptr())
+            got = dst.cpu().numpy()
+            assert (got[n:] == 0xEE).all(), "bytes written past the stream"
+            out[fused] = got[:n].copy()
+        ctx.set_option(R.OPT_MINIMIZE_FUSED, -1)
+        assert out[0].size == out[1].size and np.array_equal(out[0], out[1]), (res, R.MODE_NAMES[mode])
+        assert ctx.get_option(R.STAT_MINIMIZE_FALLBACKS) == 0
+        if w * h <= 1024 * 129:
+            frame = np.zeros(20 * w * h, dtype=np.uint8)
+            frame[:S * w * h] = U.words_to_records(hw, S, ord("3") if mode in (R.RGB_ASCII, R.BIT_ASCII) else ord("4"))
+            want = O.minimize(mode, frame, w, h)
+            assert out[1].size == want.size and np.array_equal(out[1], want), (res, R.MODE_NAMES[mode])
+
+
+def test_fused_minimize_that_gives_up_is_redone(R):
+    """RTX_OPT_MINIMIZE_FUSED = 2: a third of the blocks give up on purpose, a group's last block among them poisons its total, the
+    failure word reaches the host and the frame is minimised by the three launches: same stream, the fallback is counted -- through
+    rtx_minimize_words, rtx_update and the pipelined rtx_update_begin / _end."""
+    import torch
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    g = gold["C2_RGB_ASCII"]
+    with R.Context(W, H) as c:
+        c.set_scene(sph, pl)
+        assert c.get_option(R.OPT_MINIMIZE_FUSED) == -1
+        got = c.update(p, R.RGB_ASCII)
+        assert len(got) == g["minimized_bytes"] and O.fnv1a64(got) == g["minimized_fnv1a64"]
+        assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 0
+        c.set_option(R.OPT_MINIMIZE_FUSED, 2)
+        got = c.update(p, R.RGB_ASCII)
+        assert len(got) == g["minimized_bytes"] and O.fnv1a64(got) == g["minimized_fnv1a64"]
+        assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 1
+        host = [c.host_alloc(20 * W * H) for _ in range(2)]
+        try:
+            t0 = c.update_begin(p, R.RGB_ASCII, host[0][0])
+            t1 = c.update_begin(p, R.RGB_ASCII, host[1][0])
+            for t, hb in ((t0, host[0]), (t1, host[1])):
+                n = c.update_end(t)
+                assert n == g["minimized_bytes"] and O.fnv1a64(hb[1][:n]) == g["minimized_fnv1a64"]
+        finally:
+            for ptr, _ in host:
+                c.host_free(ptr)
+        assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 3
+        c.set_option(R.OPT_MINIMIZE_FUSED, 1)
+        got = c.update(p, R.RGB_ASCII)
+        assert len(got) == g["minimized_bytes"] and O.fnv1a64(got) == g["minimized_fnv1a64"]
+        assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 3
+        with pytest.raises(R.RtxError):
+            c.set_option(R.OPT_MINIMIZE_FUSED, 3)

@@ -178,6 +178,7 @@ def parse_args(argv=None):
     ap.add_argument("--verify", action="store_true", help="(default) check the last frame against the golden hash, outside the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the byte check of the last frame")
     ap.add_argument("--no-moving-view", action="store_true", help="N=1: skip the timing.moving_view leg")
+    ap.add_argument("--moving-step", type=float, default=MOVING_STEP_RAD, help="N=1: timing.moving_view's yaw step per frame in radians (default 0.001)")
     ap.add_argument("--no-side-legs", action="store_true", help="N=1: skip the secondary figures (modes.BIT_ASCII, end_to_end)")
     ap.add_argument("--min-timed-ms", type=float, default=50.0,
                     help="N=1: the K-step batch is repeated until this much GPU time has been measured; the median batch is reported")
@@ -567,10 +568,11 @@ def run_single(args, torch, R):
     # whose camera never rests sees.  Outside the graded number, after the verification copy.
     if args.what == "trace" and not args.no_moving_view:
         NMV = 1000 if 1000 % F == 0 else 1200          # a multiple of the frames in flight (1200: of 1..6, 8, 10, 12)
-        cams = moving_cameras(R, W, H, NMV, amplitude=NMV // 4 * MOVING_STEP_RAD)
+        MS = args.moving_step
+        cams = moving_cameras(R, W, H, NMV, step=MS, amplitude=NMV // 4 * MS)
         counter = [0]
-        mv = {"step_rad_per_frame": MOVING_STEP_RAD, "views": NMV,
-              "what": "batches of the same K frames, yaw on a triangle wave of +-%.2f rad, every frame %g rad from the one before" % (NMV // 4 * MOVING_STEP_RAD, MOVING_STEP_RAD)}
+        mv = {"step_rad_per_frame": MS, "views": NMV,
+              "what": "batches of the same K frames, yaw on a triangle wave of +-%.2f rad, every frame %g rad from the one before" % (NMV // 4 * MS, MS)}
         if F > 1:
             ring = ctx.make_submitter(cams, mode, [fbufs[i % F].data_ptr() for i in range(NMV)], [streams[i % F].cuda_stream for i in range(NMV)])
 

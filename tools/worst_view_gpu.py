@@ -6,6 +6,7 @@ library), and -- `stamps` as first argument: experiment library -- what its work
 
   python tools/worst_view_gpu.py            # timings, product library
   python tools/worst_view_gpu.py stamps     # per-workgroup candidates and lifetimes, librtx_hip_ablate.so
+  --config=C5 (or C3 ...): another BASELINE scene; --coarse: every 0.2 rad
 """
 import importlib
 import math
@@ -23,7 +24,8 @@ if stamps:
 import torch  # noqa: E402
 
 R = importlib.import_module("raytracing-in-windows-console_amd")
-p0, sph, pl = R.config_inputs("C2")
+CONFIG = next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--config=")), "C2")
+p0, sph, pl = R.config_inputs(CONFIG)
 W, H = int(p0.x), int(p0.y)
 yaws = [math.pi + 0.1 * k for k in range(25)]
 if any(a == "--coarse" for a in sys.argv[1:]):

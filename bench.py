@@ -809,18 +809,40 @@ def run_native(args, torch, R, devices, config, K, Wm, prewarm_ms, update_leg=Tr
                "gather_bytes_per_frame": ctx.get_option(R.STAT_GROUP_BYTES),
                "verified_against_golden": verified}
         if update_leg:
-            for _ in range(5):
-                ctx.update(params, mode)
-            n_up = max(10, min(K, 50))
-            tw = time.perf_counter()
-            for _ in range(n_up):
-                got = ctx.update(params, mode)
-            up_ms = (time.perf_counter() - tw) * 1e3 / n_up
             gm = golden().get("%s_%s" % (config, args.mode), {})
-            rec["end_to_end"] = {"what": "rtx_update through the group (RayTracingManager::Update's seam, RayTracingManager.cu:76-154): sharded trace, gather, "
-                                         "minimise on the root, copy of the minimised stream to pinned host memory; blocking, wall clock over %d frames" % n_up,
-                                 "ms_per_update_blocking": round(up_ms, 5), "pcie_bytes_per_update": int(len(got)),
-                                 "minimized_bytes_match_golden": (int(len(got)) == gm.get("minimized_bytes")) if gm.get("minimized_bytes") else None}
+            n_up = max(10, min(K, 50))
+
+            def time_updates():
+                for _ in range(5):
+                    ctx.update(params, mode)
+                tw = time.perf_counter()
+                for _ in range(n_up):
+                    got = ctx.update(params, mode)
+                return (time.perf_counter() - tw) * 1e3 / n_up, got
+
+            # both forms of the hand-off (RTX_OPT_GROUP_UPDATE): gathered on the root and copied over its link; every rank its own rows
+            # over its own link.  The group's default (auto: direct where the list names two or more distinct devices) is named.
+            default_direct = len(set(devices)) >= 2
+            forms = {}
+            streams = {}
+            for name, val in (("gathered", 0), ("direct", 1)):
+                if n < 2 and val == 1:
+                    continue
+                ctx.set_option(R.OPT_GROUP_UPDATE, val)
+                up_ms, got = time_updates()
+                streams[name] = bytes(got)     # (a view of the pinned buffer: valid until the next update)
+                forms[name] = {"ms_per_update_blocking": round(up_ms, 5), "pcie_bytes_per_update": int(len(got)),
+                               "minimized_bytes_match_golden": (int(len(got)) == gm.get("minimized_bytes")) if gm.get("minimized_bytes") else None}
+            if "direct" in streams:
+                forms["direct"]["same_bytes_as_gathered"] = streams["direct"] == streams["gathered"]
+            ctx.set_option(R.OPT_GROUP_UPDATE, -1)
+            used = "direct" if (default_direct and "direct" in forms) else "gathered"
+            rec["end_to_end"] = {"what": "rtx_update through the group (RayTracingManager::Update's seam, RayTracingManager.cu:76-154), blocking, wall clock over %d "
+                                         "frames.  gathered: sharded trace, gather of the pixel words, minimise on the root, copy of the minimised stream over the "
+                                         "root's PCIe link.  direct (RTX_OPT_GROUP_UPDATE): every rank traces, minimises and copies its own rows over its own link" % n_up,
+                                 "default_form": used, "direct_updates_counted": ctx.get_option(R.STAT_GROUP_DIRECT_UPDATES)}
+            rec["end_to_end"].update(forms[used])
+            rec["end_to_end"]["forms"] = forms
         return rec
     finally:
         ctx.close()

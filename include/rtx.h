@@ -137,6 +137,13 @@ enum rtx_option {
                                * caller's thread queues the root's (a rank's share is ~15 us of host work; on one thread 8 ranks cost 132 us per
                                * 1080p frame).  The call still returns only when everything is queued.  -1 auto (on where the list names two or
                                * more distinct devices; with all ranks on one GPU the threads were measured to change nothing), 0 off, 1 on */
+    RTX_OPT_GROUP_UPDATE = 18, /* device groups: how rtx_update / rtx_update_begin hand the minimised stream to the host.  0: the ranks' pixel words
+                               * are gathered on the root, which minimises the frame and copies the stream over ITS PCIe link (the whole Update is
+                               * bound by that copy: 0.33 ms per 1080p RGB frame).  1: no gather -- every rank traces its rows and the row above them,
+                               * minimises its own rows (the colour carried over from the last pixel above) and copies its part of the stream to its
+                               * place in the host buffer over its OWN link, N links at once (SURVEY.md 8(e)'s alternative).  The same bytes either
+                               * way.  -1 auto: 1 where the list names two or more distinct devices.  A HIP error on the direct path makes the group
+                               * fall back to 0 for good (RTX_STAT_GROUP_DIRECT_UPDATES counts the direct ones) */
     RTX_OPT_GROUP_WIRE = 13,  /* device groups: enum rtx_group_wire -- what travels: compact pixel words (default) or records */
     RTX_OPT_REFINE = 5        /* per-wave refinement of the candidate list in the binned kernel: -1 auto (dense scenes), 0 off, 1 on
                                * (needs at most 4 sub-tiles per workgroup and a macro tile of at most 64 x 64 pixels; otherwise it
@@ -154,6 +161,7 @@ enum rtx_stat {
     RTX_STAT_VIEW_DENSE = 108,      /* 1 while launches are planned as for a dense scene because of what earlier launches saw */
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
     RTX_STAT_BATCHED_LAUNCHES = 114, /* launches that rendered several frames' slabs at once (RTX_OPT_BATCH) */
+    RTX_STAT_GROUP_DIRECT_UPDATES = 116, /* Updates of a device group whose ranks minimised and copied their own rows (RTX_OPT_GROUP_UPDATE) */
     RTX_STAT_MINIMIZE_FALLBACKS = 115, /* fused Minimize launches redone as three launches (RTX_OPT_MINIMIZE_FUSED) */
     RTX_STAT_GROUP_SIZE = 110,      /* logical ranks of the device group this context is the root of (1: a plain context) */
     RTX_STAT_GROUP_EXCHANGE = 111,  /* the exchange the last sharded frame used: RTX_EXCHANGE_PEER_COPY or RTX_EXCHANGE_RCCL (0: none yet) */

@@ -29,6 +29,8 @@ STAT_CELL_BUILDS, STAT_CELL_PREFETCHES, STAT_CELL_HITS, STAT_CELL_PER_FRAME, STA
 OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS, OPT_GROUP_THREADS = 12, 13, 14, 15, 16
 STAT_BATCHED_LAUNCHES = 114
 OPT_MINIMIZE_FUSED = 17
+OPT_GROUP_UPDATE = 18
+STAT_GROUP_DIRECT_UPDATES = 116
 STAT_MINIMIZE_FALLBACKS = 115
 STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113
 EXCHANGE_AUTO, EXCHANGE_PEER_COPY, EXCHANGE_RCCL, EXCHANGE_RCCL_ALL = 0, 1, 2, 3

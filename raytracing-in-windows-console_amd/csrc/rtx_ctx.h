@@ -34,6 +34,7 @@ struct rtx_ctx {
     uint32_t* d_words = nullptr;    // rtx_update's pixel words (W * H; allocated on first use)
     size_t words_cap = 0;
     int64_t opt_update_words = -1;  // -1 auto (on), 0 off: rtx_update traces pixel words and minimises from them
+    uint64_t* h_pair = nullptr;     // two pinned words: a rank's stream length and failure word (rtx_update on a group, RTX_OPT_GROUP_UPDATE)
     uint64_t* d_look = nullptr;     // rtx_minw_fused's look-back tables (agg, grp: rtx_post.hip), zeroed when allocated
     size_t look_blocks = 0;         // ... sized for this many blocks
     uint32_t look_epoch = 0;        // of the last fused launch (0: none yet; never used as a tag)

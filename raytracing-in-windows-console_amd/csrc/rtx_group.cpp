@@ -117,6 +117,9 @@ struct rtx_group {
     int exchange_in_use = RTX_EXCHANGE_PEER_COPY;
     uint64_t stat_gathers = 0, stat_last_bytes = 0;
     std::vector<std::unique_ptr<RankWorker>> workers; // [r] for r >= 1 (empty: jobs run on the caller's thread)
+    int64_t opt_update = -1;                           // RTX_OPT_GROUP_UPDATE: -1 auto, 0 gather on the root, 1 every rank its own rows
+    bool update_direct_failed = false;                 // a HIP error on the direct path: gather from now on
+    uint64_t stat_direct_updates = 0;
     int64_t opt_threads = -1;                          // -1 auto (on with two or more distinct devices), 0 off, 1 on
 };
 
@@ -492,6 +495,12 @@ int set_option(rtx_ctx* root, int option, int64_t value)
         if (value == 0) stop_workers(g);
         return RTX_OK;
     }
+    if (option == RTX_OPT_GROUP_UPDATE) {
+        if (value < -1 || value > 1) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "RTX_OPT_GROUP_UPDATE: -1 (auto), 0 or 1");
+        g->opt_update = value;
+        if (value == 1) g->update_direct_failed = false; // asked for again: try again
+        return RTX_OK;
+    }
     if (option == RTX_OPT_GROUP_WIRE) {
         if (value < RTX_WIRE_AUTO || value > RTX_WIRE_COMPACT) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "RTX_OPT_GROUP_WIRE: enum rtx_group_wire");
         g->opt_wire = value;
@@ -722,6 +731,43 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
     return RTX_OK;
 }
 
+int run_on_ranks(rtx_ctx* root, const std::function<int(int, rtx_ctx*)>& fn)
+{
+    rtx_group* g = root->group;
+    const bool threaded = threads_in_use(g);
+    std::vector<int> rcs((size_t)g->n, RTX_OK);
+    for (int r = 1; r < g->n; r++) {
+        rtx_ctx* m = g->member[(size_t)r];
+        post(g, r, [&fn, r, m]() -> int { return fn(r, m); }, threaded, rcs);
+    }
+    const int rc0 = fn(0, root);
+    const int wrc = wait_posted(root, g, threaded, rcs);
+    return rc0 != RTX_OK ? rc0 : wrc;
+}
+
+bool threads_active(rtx_ctx* root) { return root->group != nullptr && threads_in_use(root->group); }
+
+bool update_direct_wanted(const rtx_ctx* root)
+{
+    const rtx_group* g = root->group;
+    if (!g || g->n < 2 || g->opt_update == 0 || g->update_direct_failed) return false;
+    if (g->opt_update == 1) return true;
+    for (int r = 1; r < g->n; r++) {
+        if (g->device[(size_t)r] != g->device[0]) return true; // (auto: where there is more than one PCIe link to use)
+    }
+    return false;
+}
+
+void update_direct_done(rtx_ctx* root, bool ok)
+{
+    rtx_group* g = root->group;
+    if (ok) {
+        g->stat_direct_updates++;
+    } else {
+        g->update_direct_failed = true;
+    }
+}
+
 int render_words(rtx_ctx* root, const rtx_params* p, int mode, const uint32_t** d_words)
 {
     rtx_group* g = root->group;
@@ -846,6 +892,8 @@ bool rtx_group_stat(const rtx_ctx* ctx, int option, int64_t* value)
     case RTX_OPT_GROUP_EXCHANGE: *value = g ? g->opt_exchange : 0; return true;
     case RTX_OPT_GROUP_WIRE: *value = g ? g->opt_wire : 0; return true;
     case RTX_OPT_GROUP_THREADS: *value = g ? g->opt_threads : 0; return true;
+    case RTX_OPT_GROUP_UPDATE: *value = g ? g->opt_update : 0; return true;
+    case RTX_STAT_GROUP_DIRECT_UPDATES: *value = g ? (int64_t)g->stat_direct_updates : 0; return true;
     default: return false;
     }
 }

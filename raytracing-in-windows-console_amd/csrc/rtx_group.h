@@ -10,6 +10,8 @@
 
 #include "rtx_ctx.h"
 
+#include <functional>
+
 struct rtx_group; // defined in rtx_group.cpp
 
 namespace rtxgroup {
@@ -35,5 +37,15 @@ int render_frames(rtx_ctx* root, size_t n, const rtx_params* params, int mode, v
 // ... as compact pixel words (W * H of them, include/rtx.h RTX_RENDER_COMPACT) in the group's word buffer on the root's device,
 // complete in stream order on the root's stream; *d_words receives the buffer.  What rtx_update minimises from.
 int render_words(rtx_ctx* root, const rtx_params* p, int mode, const uint32_t** d_words);
+
+
+// fn(rank, member) for every rank: rank 0 on the caller's thread, the others on their submission threads where those are in use
+// (RTX_OPT_GROUP_THREADS) -- and then a job may wait for its own device without holding the others up -- or one after the other.
+// Returns when all have returned; the first failure by rank, reported on the root.
+int run_on_ranks(rtx_ctx* root, const std::function<int(int, rtx_ctx*)>& fn);
+bool threads_active(rtx_ctx* root); // the ranks other than the root have submission threads (started here if they are wanted and not yet running)
+// rtx_update without a gather (RTX_OPT_GROUP_UPDATE): wanted for this group?  ... and what rtx_post.hip reports back
+bool update_direct_wanted(const rtx_ctx* root);
+void update_direct_done(rtx_ctx* root, bool ok); // ok: counted; not ok: the group gathers on its root from now on
 
 } // namespace rtxgroup

@@ -400,7 +400,9 @@ __device__ __forceinline__ uint32_t colour_key(uint32_t w)
 }
 
 // s_w[0..1] = the two words before the block's first slot (kNoWord where the frame begins), s_w[2 + li] = word of slot base + li
-__device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, uint64_t base, uint64_t n_slots, uint32_t* s_w)
+// `lead`: how many words BEFORE words[0] exist and belong to the same frame (0, or the W words of the row above a slab: a rank of
+// a device group minimises its own rows and needs the last pixel of the row before them; rtx_update on a group, RTX_OPT_GROUP_UPDATE)
+__device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, uint64_t base, uint64_t n_slots, uint32_t* s_w, uint32_t lead)
 {
     const uint32_t tid = threadIdx.x;
     const uint64_t g0 = base + (uint64_t)tid * kWPerThread;
@@ -417,7 +419,7 @@ __device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, 
         }
     }
     if (tid < 2u) {
-        s_w[tid] = base + tid >= 2u ? words[base + tid - 2u] : kNoWord;
+        s_w[tid] = base + tid + lead >= 2u ? words[(int64_t)(base + tid) - 2] : kNoWord;
     }
 }
 
@@ -433,13 +435,13 @@ __device__ __forceinline__ uint32_t first_column(uint64_t base, uint32_t W)
 // The previous ESC slot of slot g is not among the two staged before it (a frame that was only partly rendered: empty slots in
 // between): walk back through global memory.  Rare, and kept out of line so that the passes' straight-line code stays short.
 template <int MODE>
-__device__ __noinline__ uint32_t word_length_walk(const uint32_t* __restrict__ words, uint64_t g, uint32_t W, uint32_t w)
+__device__ __noinline__ uint32_t word_length_walk(const uint32_t* __restrict__ words, uint64_t g, uint32_t W, uint32_t w, uint32_t lead)
 {
     constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
-    uint64_t j = g;
-    while (j > 0) {
+    int64_t j = (int64_t)g;
+    while (j > -(int64_t)lead) {
         --j;
-        if ((uint32_t)(j % W) == W - 1u) {
+        if ((uint32_t)((uint64_t)(j + (int64_t)lead) % W) == W - 1u) { // (lead is a multiple of W)
             continue;
         }
         const uint32_t pw = words[j];
@@ -452,32 +454,33 @@ __device__ __noinline__ uint32_t word_length_walk(const uint32_t* __restrict__ w
 
 // Emitted length of slot g (column col, staged at s_w[2 + li]); `w` receives its word.  Selects, and one branch for the rare walk.
 template <int MODE>
-__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w)
+__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w,
+                                                uint32_t lead)
 {
     constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
     w = s_w[2 + li];
     // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's last column (both staged: s_w[0..1] precede the block)
     const int back = col == 0u ? 2 : 1;
     const uint32_t pw = s_w[2 + li - back];
-    const bool newline = col == W - 1u, empty = w == kNoWord, first = g == 0;
-    const bool staged = g >= (uint64_t)back && pw != kNoWord;
+    const bool newline = col == W - 1u, empty = w == kNoWord, first = g == 0 && lead == 0u;
+    const bool staged = g + lead >= (uint64_t)back && pw != kNoWord;
     uint32_t len = colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
     len = first ? S : len;     // first pixel of the frame
     len = empty ? 0u : len;    // empty slot
     len = newline ? 1u : len;
     if (!newline && !empty && !first && !staged) {
-        len = word_length_walk<MODE>(words, g, W, w);
+        len = word_length_walk<MODE>(words, g, W, w, lead);
     }
     return len;
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint32_t* block_sums)
+__global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint32_t* block_sums, uint32_t lead)
 {
     __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
     __shared__ uint32_t s_wave[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
-    stage_words(words, base, n_slots, s_w);
+    stage_words(words, base, n_slots, s_w, lead);
     uint32_t col = first_column(base, W);
     __syncthreads();
     uint32_t sum = 0;
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __res
         const uint64_t g = base + (uint64_t)li;
         uint32_t w;
         if (g < n_slots) {
-            sum += word_length<MODE>(words, s_w, g, li, col, W, w);
+            sum += word_length<MODE>(words, s_w, g, li, col, W, w, lead);
         }
         col = col + 1u == W ? 0u : col + 1u;
     }
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void rtx_min_offsets(const uint32_t* __re
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, const uint64_t* __restrict__ offsets,
-                                                             uint8_t* out)
+                                                             uint8_t* out, uint32_t lead)
 {
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
     constexpr uint32_t S = kRgb ? 20u : 12u;
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __r
     __shared__ uint32_t s_wave[kThreads / 64];
     const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
     const uint64_t G = offsets[blockIdx.x]; // where this block's output starts (the count pass's last block left it)
-    stage_words(words, base, n_slots, s_w);
+    stage_words(words, base, n_slots, s_w, lead);
     s_digits[threadIdx.x] = digits_word(threadIdx.x);
     uint32_t col = first_column(base, W);
     __syncthreads();
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __r
         wd[k] = kNoWord;
         cols[k] = col;
         if (g < n_slots) {
-            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k]);
+            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k], lead);
         }
         mine += len[k];
         col = col + 1u == W ? 0u : col + 1u;
@@ -643,7 +646,7 @@ __device__ __forceinline__ bool look_wait(const uint64_t* p, uint32_t epoch, uin
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng,
-                                                           uint32_t epoch, uint32_t max_polls, uint8_t* out, uint64_t* total_out)
+                                                           uint32_t epoch, uint32_t max_polls, uint8_t* out, uint64_t* total_out, uint32_t lead)
 {
     constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
     constexpr uint32_t S = kRgb ? 20u : 12u;
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __res
     uint32_t* s_wave = s_w + 2 + kWSlotsPerBlock + 2;
     const uint32_t b = blockIdx.x;
     const uint64_t base = (uint64_t)b * kWSlotsPerBlock;
-    stage_words(words, base, n_slots, s_w);
+    stage_words(words, base, n_slots, s_w, lead);
     s_digits[threadIdx.x] = digits_word(threadIdx.x);
     uint32_t col = first_column(base, W);
     __syncthreads();
@@ -676,7 +679,7 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __res
         wd[k] = kNoWord;
         cols[k] = col;
         if (g < n_slots) {
-            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k]);
+            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k], lead);
         }
         mine += len[k];
         col = col + 1u == W ? 0u : col + 1u;
@@ -851,7 +854,7 @@ size_t words_scan_bytes(uint64_t n_slots)
 }
 
 // Minimize from W*H pixel words (every mode but SDL) on the context's stream as three launches; scratch laid out as launch_minimize's.
-int launch_minimize_words_chain(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
+int launch_minimize_words_chain(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total, uint32_t lead)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const unsigned n_blocks = (unsigned)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock);
@@ -861,9 +864,9 @@ int launch_minimize_words_chain(rtx_ctx* ctx, void* d_scan, int mode, size_t w, 
     hipStream_t st = ctx->stream;
 #define RTX_MINW(M)                                                                                                                        \
     do {                                                                                                                                   \
-        hipLaunchKernelGGL((rtx::rtx_minw_count<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums);      \
+        hipLaunchKernelGGL((rtx::rtx_minw_count<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, sums, lead);      \
         hipLaunchKernelGGL(rtx::rtx_min_offsets, dim3(1), dim3(rtx::kThreads), 0, st, sums, n_blocks, offsets, total);                      \
-        hipLaunchKernelGGL((rtx::rtx_minw_scatter<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, offsets, d_out); \
+        hipLaunchKernelGGL((rtx::rtx_minw_scatter<M>), dim3(n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, offsets, d_out, lead); \
     } while (0)
     switch (mode) {
     case RTX_BIT_ASCII: RTX_MINW(RTX_K_BIT_ASCII); break;
@@ -905,12 +908,12 @@ int ensure_look_tables(rtx_ctx* ctx, size_t n_blocks)
 // Minimize from W*H pixel words on the context's stream: one launch (rtx_minw_fused, RTX_OPT_MINIMIZE_FUSED) or the three above.
 // (*d_total)[0] will hold the stream's length; after a fused launch (ctx->min_fused_epoch != 0) (*d_total)[1] == that epoch says
 // that blocks gave up: settle_minimize_words then redoes the frame with the three launches.
-int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total)
+int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total, uint32_t lead = 0)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const uint64_t n_blocks = (n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock;
     ctx->min_fused_epoch = 0;
-    if (ctx->opt_min_fused == 0 || n_blocks > (1u << 24)) return launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, d_total);
+    if (ctx->opt_min_fused == 0 || n_blocks > (1u << 24)) return launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, d_total, lead);
     int rc = ensure_look_tables(ctx, (size_t)n_blocks);
     if (rc != RTX_OK) return rc;
     if (++ctx->look_epoch == 0u) {
@@ -926,7 +929,7 @@ int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
     const uint32_t polls = ctx->opt_min_fused == 2 ? 0u : rtx::kLookPolls;
     hipStream_t st = ctx->stream;
 #define RTX_MINF(M) \
-    hipLaunchKernelGGL((rtx::rtx_minw_fused<M>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, agg, grp, ng, epoch, polls, d_out, total)
+    hipLaunchKernelGGL((rtx::rtx_minw_fused<M>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, st, d_words, n_slots, (uint32_t)w, agg, grp, ng, epoch, polls, d_out, total, lead)
     switch (mode) {
     case RTX_BIT_ASCII: RTX_MINF(RTX_K_BIT_ASCII); break;
     case RTX_BIT_PIXEL: RTX_MINF(RTX_K_BIT_PIXEL); break;
@@ -944,7 +947,8 @@ int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
 
 // got[0], got[1]: the two words at *d_total as the host read them after the launches of launch_minimize_words.  A fused launch
 // whose blocks gave up is redone here as three launches (the stream is synchronised again); *total = the stream's length.
-int settle_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, const uint64_t got[2], uint64_t* total)
+int settle_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, const uint64_t got[2], uint64_t* total,
+                          uint32_t lead = 0)
 {
     *total = got[0];
     const uint32_t epoch = ctx->min_fused_epoch;
@@ -952,7 +956,7 @@ int settle_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
     if (epoch == 0u || got[1] != (uint64_t)epoch) return RTX_OK;
     ctx->stat_min_fallbacks++;
     uint64_t* d_total = nullptr;
-    int rc = launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, &d_total);
+    int rc = launch_minimize_words_chain(ctx, d_scan, mode, w, h, d_words, d_out, &d_total, lead);
     if (rc != RTX_OK) return rc;
     RTX_HIP(ctx, hipMemcpyAsync(total, d_total, sizeof *total, hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -986,6 +990,113 @@ int trace_words(rtx_ctx* ctx, const rtx_params* p, int mode, uint32_t** own, siz
     if (rc != RTX_OK) return rc;
     if ((rc = rtx_render_rows(ctx, p, mode, 0, (size_t)p->y, *own, 0, ctx->stream, RTX_RENDER_COMPACT)) != RTX_OK) return rc;
     *d_words = *own;
+    return RTX_OK;
+}
+
+// rtx_update on a device group WITHOUT a gather (RTX_OPT_GROUP_UPDATE): the whole Update is bound by the copy of the minimised
+// stream over one PCIe link, and a group has one link per device.  Every rank traces its rows as pixel words -- and the row above
+// them, whose last pixel is the colour its first pixel is compared with (RayTracingManager.cu:181-319 carries the last emitted colour
+// across rows) -- minimises its own rows (launch_minimize_words with `lead` = W) and, once the lengths of the ranks before it are
+// known on the host, copies its part of the stream to its place in host_out from its own device.  The ranks' parts, in rank
+// order, are the bytes the root would have made of the gathered frame.  false in *done: nothing was delivered, gather instead.
+int update_group_direct(rtx_ctx* root, const rtx_params* p, int mode, void* host_out, size_t* out_bytes)
+{
+    const int N = rtx_group_size(root);
+    const size_t W = (size_t)p->x, H = (size_t)p->y;
+    struct Part {
+        size_t row0 = 0, rows = 0, bytes = 0, offset = 0;
+    };
+    std::vector<Part> part((size_t)N);
+    for (int r = 0; r < N; r++) {
+        if (rtx_group_rows(root, H, r, &part[(size_t)r].row0, &part[(size_t)r].rows) != RTX_OK) return rtx_fail(root, RTX_ERR_INVALID_ARGUMENT, "rtx_group_rows failed");
+    }
+    struct Queued {
+        const uint32_t* d_words = nullptr;
+        uint32_t lead = 0;
+    };
+    std::vector<Queued> queued((size_t)N);
+    // a rank's device work: trace (its rows and the one above), minimise, the two words of the result on their way to the host
+    auto queue_rows = [&](int r, rtx_ctx* m) -> int {
+        Part& q = part[(size_t)r];
+        if (q.rows == 0) return RTX_OK;
+        RTX_HIP(m, hipSetDevice(m->device));
+        const size_t above = q.row0 > 0 ? 1u : 0u;
+        int rc2 = ensure_words_buffer(m, &m->d_words, &m->words_cap, (q.rows + above) * W);
+        if (rc2 != RTX_OK) return rc2;
+        if (!m->h_pair && hipHostMalloc((void**)&m->h_pair, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+            m->h_pair = nullptr;
+            return rtx_fail(m, RTX_ERR_OUT_OF_MEMORY, "hipHostMalloc failed for a rank's stream length");
+        }
+        if ((rc2 = rtx_render_rows(m, p, mode, q.row0 - above, q.rows + above, m->d_words, q.row0 - above, m->stream, RTX_RENDER_COMPACT)) != RTX_OK) return rc2;
+        const uint64_t n_slots = (uint64_t)W * q.rows;
+        if ((rc2 = ensure_min_buffers(m, (size_t)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock), true)) != RTX_OK) return rc2;
+        queued[(size_t)r].d_words = m->d_words + above * W;
+        queued[(size_t)r].lead = (uint32_t)(above * W);
+        uint64_t* d_total = nullptr;
+        if ((rc2 = launch_minimize_words(m, m->d_scan, mode, W, q.rows, queued[(size_t)r].d_words, m->d_min, &d_total, queued[(size_t)r].lead)) != RTX_OK) return rc2;
+        RTX_HIP(m, hipMemcpyAsync(m->h_pair, d_total, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, m->stream));
+        return RTX_OK;
+    };
+    auto await_rows = [&](int r, rtx_ctx* m) -> int {
+        Part& q = part[(size_t)r];
+        if (q.rows == 0) return RTX_OK;
+        RTX_HIP(m, hipSetDevice(m->device));
+        RTX_HIP(m, hipStreamSynchronize(m->stream));
+        uint64_t total = 0;
+        const int rc2 = settle_minimize_words(m, m->d_scan, mode, W, q.rows, queued[(size_t)r].d_words, m->d_min, m->h_pair, &total, queued[(size_t)r].lead);
+        if (rc2 != RTX_OK) return rc2;
+        q.bytes = (size_t)total;
+        return RTX_OK;
+    };
+    auto queue_copy = [&](int r, rtx_ctx* m) -> int {
+        const Part& q = part[(size_t)r];
+        if (q.bytes == 0) return RTX_OK;
+        RTX_HIP(m, hipSetDevice(m->device));
+        RTX_HIP(m, hipMemcpyAsync((uint8_t*)host_out + q.offset, m->d_min, q.bytes, hipMemcpyDeviceToHost, m->stream));
+        return RTX_OK;
+    };
+    auto await_copy = [&](int r, rtx_ctx* m) -> int {
+        if (part[(size_t)r].bytes == 0) return RTX_OK;
+        RTX_HIP(m, hipSetDevice(m->device));
+        RTX_HIP(m, hipStreamSynchronize(m->stream));
+        return RTX_OK;
+    };
+    // With a submission thread per rank a rank queues and waits in one go (the ranks wait side by side); on the caller's thread alone
+    // everything is queued first, so that the ranks' device work still overlaps.
+    const bool threads = rtxgroup::threads_active(root);
+    int rc;
+    if (threads) {
+        rc = rtxgroup::run_on_ranks(root, [&](int r, rtx_ctx* m) -> int {
+            const int rc2 = queue_rows(r, m);
+            return rc2 != RTX_OK ? rc2 : await_rows(r, m);
+        });
+    } else {
+        rc = rtxgroup::run_on_ranks(root, queue_rows);
+        const int rcw = rtxgroup::run_on_ranks(root, await_rows); // (also after a failure: nothing may still be running on a rank's buffers)
+        if (rc == RTX_OK) rc = rcw;
+    }
+    if (rc != RTX_OK) {
+        (void)hipSetDevice(root->device);
+        return rc;
+    }
+    size_t at = 0;
+    for (int r = 0; r < N; r++) {
+        part[(size_t)r].offset = at;
+        at += part[(size_t)r].bytes;
+    }
+    if (threads) {
+        rc = rtxgroup::run_on_ranks(root, [&](int r, rtx_ctx* m) -> int {
+            const int rc2 = queue_copy(r, m);
+            return rc2 != RTX_OK ? rc2 : await_copy(r, m);
+        });
+    } else {
+        rc = rtxgroup::run_on_ranks(root, queue_copy);
+        const int rcw = rtxgroup::run_on_ranks(root, await_copy);
+        if (rc == RTX_OK) rc = rcw;
+    }
+    RTX_HIP(root, hipSetDevice(root->device));
+    if (rc != RTX_OK) return rc;
+    *out_bytes = at;
     return RTX_OK;
 }
 
@@ -1111,6 +1222,16 @@ int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int 
         if (params->x == 0 || params->y == 0 || 20 * (uint64_t)params->x * (uint64_t)params->y > ctx->capacity) {
             return rtx_fail(ctx, params->x && params->y ? RTX_ERR_TOO_LARGE : RTX_ERR_INVALID_ARGUMENT, "frame larger than the context was created for, or empty");
         }
+        if (rtxgroup::update_direct_wanted(ctx)) {
+            // no gather: every rank minimises its own rows and copies them over its own PCIe link
+            rc = update_group_direct(ctx, params, mode, host_out, &n);
+            rtxgroup::update_direct_done(ctx, rc == RTX_OK);
+            if (rc == RTX_OK) {
+                *out_bytes = n;
+                return RTX_OK;
+            }
+            (void)hipGetLastError(); // (the group gathers on its root from now on; this frame too)
+        }
         const uint32_t* d_words = nullptr;
         if ((rc = trace_words(ctx, params, mode, &ctx->d_words, &ctx->words_cap, &d_words)) != RTX_OK) return rc;
         if ((rc = rtx_minimize_words(ctx, mode, (size_t)params->x, (size_t)params->y, d_words, nullptr, &n)) != RTX_OK) return rc;
@@ -1181,6 +1302,22 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     }
     int rc;
     if (run_physics && (rc = rtx_update_objects(ctx, dt)) != RTX_OK) return rc;
+    if (from_words && rtxgroup::update_direct_wanted(ctx)) {
+        // a group whose ranks minimise and copy their own rows (RTX_OPT_GROUP_UPDATE): N links carry the stream at once, which is
+        // worth more than the overlap of one link's copy with the next trace -- the frame is complete when this call returns
+        size_t n = 0;
+        rc = update_group_direct(ctx, params, mode, host_out, &n);
+        rtxgroup::update_direct_done(ctx, rc == RTX_OK);
+        if (rc == RTX_OK) {
+            sl.bytes = n;
+            RTX_HIP(ctx, hipEventRecord(sl.ev_copied, ctx->copy_stream));
+            sl.busy = true;
+            *ticket = (int)si;
+            ctx->upd_next = si ^ 1u;
+            return RTX_OK;
+        }
+        (void)hipGetLastError(); // (the group gathers on its root from now on; this frame too)
+    }
     uint64_t* d_total = nullptr;
     const uint32_t* d_words = nullptr;
     if (from_words) {

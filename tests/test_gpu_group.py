@@ -293,3 +293,96 @@ def test_submit_frames_on_a_group_shards_a_chunk_of_frames_per_call(R, ranks, wi
         for r in range(ranks):
             assert g.member_option(r, R.STAT_BATCHED_LAUNCHES) == 2 * per_call, (r, chunk, g.member_kernel(r))
         assert g.get_option(R.STAT_GROUP_GATHERS) == 2 * n
+
+
+# ---- rtx_update without a gather: every rank minimises and copies its own rows (RTX_OPT_GROUP_UPDATE)
+
+@pytest.mark.parametrize("ranks,W,H", [(7, 400, 150), (5, 97, 41), (8, 64, 3), (2, 333, 1), (16, 320, 180), (3, 1, 9), (4, 2, 8)])
+def test_direct_update_is_the_gathered_update(R, ranks, W, H):
+    """RTX_OPT_GROUP_UPDATE = 1: each rank traces its rows and the row above them, minimises its own rows with the colour carried over
+    from the last pixel above, and copies its part of the stream to its place in the host buffer.  Ragged and empty slabs, widths of
+    one and two slots, every mode (SDL has no words: it takes the other path), both forms of the minimise pass: the bytes of the
+    oracle's Minimize of the oracle's frame, and of the same group's gathered Update."""
+    sc = O.Scene.reference_default()
+    p = R.camera_params(W, H)
+    with R.Context(W, H, devices=[0] * ranks) as c:
+        c.set_reference_default_scene()
+        assert c.get_option(R.OPT_GROUP_UPDATE) == -1          # auto: one device here, so the root gathers
+        for mode in range(6):
+            want = O.minimize(mode, O.render(U.oracle_params(p), sc, mode), W, H)
+            c.set_option(R.OPT_GROUP_UPDATE, 0)
+            gathered = c.update(p, mode).copy()
+            before = c.get_option(R.STAT_GROUP_DIRECT_UPDATES)
+            c.set_option(R.OPT_GROUP_UPDATE, 1)
+            for fused in (1, 0):
+                c.set_option(R.OPT_MINIMIZE_FUSED, fused)
+                got = c.update(p, mode).copy()
+                assert got.size == want.size and np.array_equal(got, want), (R.MODE_NAMES[mode], fused)
+                assert np.array_equal(got, gathered)
+            c.set_option(R.OPT_MINIMIZE_FUSED, -1)
+            assert c.get_option(R.STAT_GROUP_DIRECT_UPDATES) - before == (0 if mode == R.SDL else 2)
+        with pytest.raises(R.RtxError):
+            c.set_option(R.OPT_GROUP_UPDATE, 2)
+    with R.Context(W, H) as one:
+        with pytest.raises(R.RtxError):
+            one.set_option(R.OPT_GROUP_UPDATE, 1)            # not a group
+
+
+def test_direct_update_c2_golden_with_physics_and_pipelined(R):
+    """Config 2 through 8 logical ranks with RTX_OPT_GROUP_UPDATE = 1: the committed golden stream (both record sizes); then a moving
+    scene, frame after frame against a single-device context, blocking and through rtx_update_begin / _end; and a fused minimise
+    whose blocks give up (RTX_OPT_MINIMIZE_FUSED = 2) on every rank."""
+    gold = U.load_golden()
+    p, sph, pl = R.config_inputs("C2")
+    W, H = int(p.x), int(p.y)
+    with R.Context(W, H, devices=[0] * 8) as g:
+        g.set_scene(sph, pl)
+        g.set_option(R.OPT_GROUP_UPDATE, 1)
+        for threads in (0, 1):      # everything queued, then awaited, by the caller's thread; a rank's thread queues and waits in one go
+            g.set_option(R.OPT_GROUP_THREADS, threads)
+            for mode in (R.RGB_ASCII, R.BIT_ASCII):
+                ref = gold["C2_%s" % R.MODE_NAMES[mode]]
+                got = g.update(p, mode)
+                assert len(got) == ref["minimized_bytes"] and O.fnv1a64(got) == ref["minimized_fnv1a64"], (threads, R.MODE_NAMES[mode])
+        g.set_option(R.OPT_MINIMIZE_FUSED, 2)
+        got = g.update(p, R.RGB_ASCII)
+        ref = gold["C2_RGB_ASCII"]
+        assert len(got) == ref["minimized_bytes"] and O.fnv1a64(got) == ref["minimized_fnv1a64"]
+        assert sum(g.member_option(r, R.STAT_MINIMIZE_FALLBACKS) for r in range(8)) == 8
+    W, H, n = 640, 360, 900
+    rng = np.random.default_rng(5)
+    p = R.camera_params(W, H)
+    sph, pl = R.synth_scene(4, n, 1, p.element1, p.element2)
+    with R.Context(W, H, devices=[0, 0, 0]) as g, R.Context(W, H) as one:
+        speeds = (rng.integers(50, 300, n) / 100.0).astype(np.float32)
+        for c in (g, one):
+            c.set_scene(sph, pl)
+            for i in range(0, n, 2):
+                c.set_sphere_motion(i, 1 if i % 4 else -1, float(speeds[i]))
+        g.set_option(R.OPT_GROUP_UPDATE, 1)
+        for f in range(4):
+            mode = (R.RGB_ASCII, R.BIT_PIXEL)[f % 2]
+            a = g.update(p, mode, dt=0.05, run_physics=True).copy()
+            b = one.update(p, mode, dt=0.05, run_physics=True).copy()
+            assert a.size == b.size and np.array_equal(a, b), f
+        nbytes = 20 * W * H
+        bufs = [g.host_alloc(nbytes) for _ in range(2)] + [one.host_alloc(nbytes)]
+        try:
+            tickets = []
+            for f in range(4):
+                if len(tickets) == 2:
+                    t, idx = tickets.pop(0)
+                    na = g.update_end(t)
+                    tb = one.update_begin(p, R.RGB_ASCII, bufs[2][0], dt=0.05, run_physics=True)
+                    nb = one.update_end(tb)
+                    assert na == nb and np.array_equal(bufs[idx][1][:na], bufs[2][1][:nb]), f
+                tickets.append((g.update_begin(p, R.RGB_ASCII, bufs[f % 2][0], dt=0.05, run_physics=True), f % 2))
+            for t, idx in tickets:
+                na = g.update_end(t)
+                tb = one.update_begin(p, R.RGB_ASCII, bufs[2][0], dt=0.05, run_physics=True)
+                nb = one.update_end(tb)
+                assert na == nb and np.array_equal(bufs[idx][1][:na], bufs[2][1][:nb])
+        finally:
+            for c, (ptr, _) in ((g, bufs[0]), (g, bufs[1]), (one, bufs[2])):
+                c.host_free(ptr)
+        assert g.get_option(R.STAT_GROUP_DIRECT_UPDATES) == 8

@@ -13,9 +13,11 @@ for d in 0 0,0 0,0,0,0 0,0,0,0,0,0,0,0; do
 import json,sys
 d=json.loads(sys.stdin.read())
 e=d.get('end_to_end') or {}
-print('ranks %d  frames/call %2d  %7.2f us/frame (events)  %7.2f us/frame (wall)  verified %s  gather %d B/frame  update %.3f ms  | %s' % (
+f=e.get('forms') or {}
+print('ranks %d  frames/call %2d  %7.2f us/frame (events)  %7.2f us/frame (wall)  verified %s  gather %d B/frame  update gathered %.3f ms, direct %.3f ms (same bytes: %s)  | %s' % (
     d['logical_ranks'], d['config']['frames_per_call'], d['ms_per_step']*1e3, d['timing']['wall_ms_per_step_median']*1e3,
-    d['verified_against_golden'], d['gather_bytes_per_frame'], e.get('ms_per_update_blocking', float('nan')), d['config']['parallelism'].split('exchange: ')[1][:40]))
+    d['verified_against_golden'], d['gather_bytes_per_frame'], (f.get('gathered') or {}).get('ms_per_update_blocking', float('nan')),
+    (f.get('direct') or {}).get('ms_per_update_blocking', float('nan')), (f.get('direct') or {}).get('same_bytes_as_gathered'), d['config']['parallelism'].split('exchange: ')[1][:40]))
 "
    done
   done

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,21 @@ struct HostPlane {
 };
 
 struct rtx_group; // rtx_group.cpp: the device group a context is the root of
+
+// bit casts (the creation index of an object travels in the .w of its float4s)
+inline float bits_to_float(uint32_t u)
+{
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+inline uint32_t float_to_bits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
 
 struct rtx_ctx {
     int device = 0;

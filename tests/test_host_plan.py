@@ -21,7 +21,7 @@ def test_host_planners_under_sanitizers(tmp_path):
 
 def test_resident_workgroups_per_cu_is_one_constant():
     """The trace kernels' occupancy (RTX_WAVES_PER_EU) is named in one place on the host side: rtxplan::kResidentPerCU."""
-    api = open(os.path.join(ROOT, "raytracing-in-windows-console_amd", "csrc", "rtx_api.cpp")).read()
+    api = open(os.path.join(ROOT, "raytracing-in-windows-console_amd", "csrc", "rtx_render.cpp")).read()
     assert "7ull *" not in api and "resident = 7u" not in api
     assert "rtxplan::resident_slots" in api and "rtxplan::kResidentPerCU" in api
     plan = open(os.path.join(ROOT, "raytracing-in-windows-console_amd", "csrc", "rtx_plan.hpp")).read()

@@ -586,3 +586,31 @@ def test_fused_minimize_that_gives_up_is_redone(R):
         assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 3
         with pytest.raises(R.RtxError):
             c.set_option(R.OPT_MINIMIZE_FUSED, 3)
+
+
+def test_fused_minimize_beside_other_launches(R):
+    """The one-launch Minimize waits only for blocks of smaller index, which the hardware dispatches first -- also when another
+    context keeps the GPU's workgroup slots busy with frames in flight on four streams of its own.  150 Updates of config 2 beside a
+    stream of 4K frames: the golden stream every time, and not one launch that gave up and was redone."""
+    import torch
+    gold = U.load_golden()["C2_RGB_ASCII"]
+    p2, sph2, pl2 = R.config_inputs("C2")
+    p3, sph3, pl3 = R.config_inputs("C3")
+    W3, H3 = int(p3.x), int(p3.y)
+    with R.Context(int(p2.x), int(p2.y)) as c, R.Context(W3, H3) as busy:
+        c.set_scene(sph2, pl2)
+        busy.set_scene(sph3, pl3)
+        streams = [torch.cuda.Stream() for _ in range(4)]
+        bufs = [torch.empty(20 * W3 * H3, dtype=torch.uint8, device="cuda") for _ in range(4)]
+        sub = busy.make_submitter([p3] * 8, R.RGB_ASCII, [bufs[i % 4].data_ptr() for i in range(8)], [streams[i % 4].cuda_stream for i in range(8)])
+        torch.cuda.synchronize()
+        for k in range(150):
+            if k % 3 == 0:
+                sub(8, 0)                   # ~0.7 ms of 4K frames queued beside the next Updates
+            got = c.update(p2, R.RGB_ASCII)
+            assert len(got) == gold["minimized_bytes"], k
+            if k % 25 == 0:
+                assert O.fnv1a64(got) == gold["minimized_fnv1a64"], k
+        torch.cuda.synchronize()
+        assert O.fnv1a64(c.update(p2, R.RGB_ASCII)) == gold["minimized_fnv1a64"]
+        assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 0

@@ -88,3 +88,66 @@ def test_moving_camera_over_reused_cell_lists_against_the_oracle(R):
                 ref = O.render_row(op, sc, O.RGB_ASCII, r)
                 assert np.array_equal(host[r], ref), "frame %d row %d: %s" % (f, r, U.first_diff(host[r], ref, S, W))
         assert c.get_option(R.STAT_CELL_HITS) - hits0 >= 12     # most frames were served by lists built for an earlier camera
+
+
+def test_minimize_from_words_fuzz(R):
+    """Bounded, fixed seed: made-up pixel words (runs of equal colour, misses, empty slots from none to nearly all, W from 1 to 3000, up
+    to 600 000 slots) through rtx_minimize_words as one launch and as three -- equal to each other and to the oracle's Minimize of
+    the expanded records."""
+    import torch
+    rng = np.random.default_rng(20261005)
+    ctx = R.Context(3000, 400)
+    t0 = time.time()
+    cases = 0
+    while cases < 60 and time.time() - t0 < 12.0:
+        W = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 1024, int(rng.integers(4, 3000))]))
+        H = int(rng.integers(1, max(2, min(400, 600000 // W))))
+        mode = int(rng.integers(0, 5))
+        holes = float(rng.choice([0.0, 0.0, 0.01, 0.3, 0.9, 0.999]))
+        runs = float(rng.choice([0.0, 0.5, 0.9, 0.99]))
+        S = 20 if mode >= R.RGB_ASCII else 12
+        hw = U.random_words(rng, W, H, runs=runs, holes=holes)
+        if mode < R.RGB_ASCII:
+            hw = np.where((hw != 0) & (hw != 0xFFFFFFFF), hw & np.uint32(0xFF0000FF), hw).astype(np.uint32)
+        words = torch.from_numpy(hw.view(np.int32)).cuda()
+        frame = np.zeros(20 * W * H, dtype=np.uint8)
+        frame[:S * W * H] = U.words_to_records(hw, S, ord("3") if mode in (R.RGB_ASCII, R.BIT_ASCII) else ord("4"))
+        want = O.minimize(mode, frame, W, H)
+        for fused in (1, 0):
+            ctx.set_option(R.OPT_MINIMIZE_FUSED, fused)
+            dst = torch.full((S * W * H + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            n = ctx.minimize_words(mode, W, H, words.data_ptr(), d_out=dst.data_ptr())
+            got = dst.cpu().numpy()
+            assert n == want.size and np.array_equal(got[:n], want), (W, H, R.MODE_NAMES[mode], holes, runs, fused)
+            assert (got[n:] == 0xEE).all()
+        cases += 1
+    fallbacks = ctx.get_option(R.STAT_MINIMIZE_FALLBACKS)
+    ctx.close()
+    assert cases >= 20 and fallbacks == 0
+
+
+def test_group_direct_update_fuzz(R):
+    """Bounded, fixed seed: random group sizes, frame sizes and modes; rtx_update with every rank minimising its own rows (the row above
+    as lead) against a single-device context on the same scene."""
+    rng = np.random.default_rng(777)
+    t0 = time.time()
+    cases = 0
+    while cases < 14 and time.time() - t0 < 12.0:
+        ranks = int(rng.integers(2, 10))
+        W = int(rng.choice([1, 2, 5, 64, 333, int(rng.integers(3, 900))]))
+        H = int(rng.integers(1, 260))
+        p = R.camera_params(W, H)
+        sph, pl = R.synth_scene(int(rng.integers(1, 50)), int(rng.integers(1, 400)), 1, p.element1, p.element2)
+        with R.Context(W, H, devices=[0] * ranks) as g, R.Context(W, H) as one:
+            for c in (g, one):
+                c.set_scene(sph, pl)
+            g.set_option(R.OPT_GROUP_UPDATE, 1)
+            g.set_option(R.OPT_GROUP_THREADS, int(rng.integers(0, 2)))
+            for mode in rng.permutation(5)[:2]:
+                a = g.update(p, int(mode)).copy()
+                b = one.update(p, int(mode)).copy()
+                assert a.size == b.size and np.array_equal(a, b), (ranks, W, H, R.MODE_NAMES[int(mode)])
+            assert g.get_option(R.STAT_GROUP_DIRECT_UPDATES) == 2
+        cases += 1
+    assert cases >= 5

@@ -499,24 +499,6 @@ def test_update_from_words_and_from_records_hand_over_the_same_stream(R):
 
 # ---- the one-launch form of Minimize from words (rtx_minw_fused, RTX_OPT_MINIMIZE_FUSED)
 
-def _random_words(rng, w, h, runs, holes):
-    """Pixel words of a made-up frame: colours in runs of random length (so that escapes are elided), misses, optional empty slots."""
-    n = w * h
-    colours = rng.integers(0, 1 << 24, size=n, dtype=np.uint32)
-    keep = rng.random(n) < runs
-    idx = np.where(~keep, np.arange(n), 0)
-    np.maximum.accumulate(idx, out=idx)
-    colours = colours[idx]
-    glyph = rng.integers(33, 127, size=n, dtype=np.uint32)
-    words = (glyph << 24) | colours
-    words[rng.random(n) < 0.2] = 0                       # misses
-    if holes:
-        words[rng.random(n) < holes] = 0xFFFFFFFF
-    hw = words.reshape(h, w)
-    hw[:, w - 1] = 0xFFFFFFFF                            # the newline column as the trace kernel leaves it
-    return hw.reshape(-1).astype(np.uint32)
-
-
 @pytest.mark.parametrize("res", [(1024, 1), (1024, 63), (1024, 64), (1024, 65), (1024, 129), (1920, 1080), (3840, 2160), (977, 331), (5, 3)])
 def test_fused_minimize_is_the_three_launch_minimize(R, ctx, res):
     """One launch with a two-level look-back (64 blocks per group: frames of 1, 63, 64, 65, 129, 2025 and 8100 blocks) against the
@@ -527,7 +509,7 @@ def test_fused_minimize_is_the_three_launch_minimize(R, ctx, res):
     rng = np.random.default_rng(w * 7919 + h)
     for mode, holes in ((R.RGB_ASCII, 0.0), (R.BIT_PIXEL, 0.0), (R.RGB_NORMALS, 0.05)):
         S = 20 if mode >= R.RGB_ASCII else 12
-        hw = _random_words(rng, w, h, runs=0.7, holes=holes)
+        hw = U.random_words(rng, w, h, runs=0.7, holes=holes)
         if mode < R.RGB_ASCII:
             hw = np.where((hw != 0) & (hw != 0xFFFFFFFF), hw & np.uint32(0xFF0000FF), hw).astype(np.uint32)   # an index and a glyph
         words = torch.from_numpy(hw.view(np.int32)).cuda()

@@ -149,3 +149,21 @@ def words_to_records(words, S, hit_kind):
     rec[hit, S - 1] = (words[hit] >> np.uint32(24)).astype(np.uint8)
     rec[words == 0xFFFFFFFF] = 0
     return rec.reshape(-1)
+
+
+def random_words(rng, w, h, runs, holes):
+    """Pixel words of a made-up frame: colours in runs of random length (so that escapes are elided), misses, optional empty slots."""
+    n = w * h
+    colours = rng.integers(0, 1 << 24, size=n, dtype=np.uint32)
+    keep = rng.random(n) < runs
+    idx = np.where(~keep, np.arange(n), 0)
+    np.maximum.accumulate(idx, out=idx)
+    colours = colours[idx]
+    glyph = rng.integers(33, 127, size=n, dtype=np.uint32)
+    words = (glyph << 24) | colours
+    words[rng.random(n) < 0.2] = 0                       # misses
+    if holes:
+        words[rng.random(n) < holes] = 0xFFFFFFFF
+    hw = words.reshape(h, w)
+    hw[:, w - 1] = 0xFFFFFFFF                            # the newline column as the trace kernel leaves it
+    return hw.reshape(-1).astype(np.uint32)

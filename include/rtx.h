@@ -127,9 +127,9 @@ enum rtx_option {
                                * memory traffic (1080p RGB: 8.3 MB written + 16.6 MB read instead of 41.5 + 83).  The context's frame buffer
                                * is then not written by an Update (it keeps what the last rtx_render left).  -1 auto (on), 0 off (records:
                                * the frame buffer holds the frame after every Update, as the reference's m_deviceResultArray does), 1 on */
-    RTX_OPT_MINIMIZE_FUSED = 17, /* the word form of Minimize (rtx_minimize_words, rtx_update with RTX_OPT_UPDATE_WORDS) as ONE launch: every block counts
+    RTX_OPT_MINIMIZE_FUSED = 17, /* Minimize -- from pixel words (rtx_minimize_words, rtx_update with RTX_OPT_UPDATE_WORDS) and from records (rtx_minimize) -- as ONE launch: every block counts
                                * its slots, publishes its length and finds its place in the stream by a two-level look-back over the lengths of
-                               * the blocks before it, instead of three launches (count, offsets, scatter) that read the words twice.  A launch
+                               * the blocks before it, instead of three launches (count, offsets, scatter; two for records) that read their input twice.  A launch
                                * whose blocks gave up waiting (bounded polling; never seen) is redone as three launches: RTX_STAT_MINIMIZE_FALLBACKS.
                                * -1 auto (on), 0 off, 1 on, 2 on with blocks that give up on purpose (tests of that path) */
     RTX_OPT_GROUP_EXCHANGE = 12, /* device groups (rtx_group_create): enum rtx_group_exchange -- how the slabs reach the root */

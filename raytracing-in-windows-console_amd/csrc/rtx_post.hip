@@ -644,6 +644,89 @@ __device__ __forceinline__ bool look_wait(const uint64_t* p, uint32_t epoch, uin
     }
 }
 
+// The look-back of block b, whose length n is already published in agg[b]: done by the first wave, the block's offset in *s_G and
+// the verdict in *s_ok (both in LDS), a barrier, and the verdict returned to every thread.  The barrier also completes whatever the
+// block wrote to LDS before the call (its output image).
+__device__ __forceinline__ bool look_back(uint32_t b, uint32_t n, const uint64_t* agg, uint64_t* grp, uint32_t ng, uint32_t epoch, uint32_t max_polls, uint64_t* s_G,
+                                          uint32_t* s_ok)
+{
+    if (threadIdx.x < 64u) {
+        const uint32_t lane = threadIdx.x;
+        const uint32_t g = b / kLookGroup, first = g * kLookGroup;
+        uint64_t before = 0, in_group = 0;
+        bool ok_group = true, ok_before = true;
+        if (first + lane < b) {
+            uint32_t v;
+            ok_group = look_wait(&agg[first + lane], epoch, max_polls, v);
+            in_group = v;
+        }
+        if (max_polls == 0u && b % 3u == 1u) {
+            ok_group = false; // (tests: a launch whose blocks give up, RTX_OPT_MINIMIZE_FUSED = 2)
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            in_group += __shfl_xor(in_group, d);
+        }
+        ok_group = __all(ok_group);
+        if (b % kLookGroup == kLookGroup - 1u) {
+            // the group's total, once per replica (lane r writes replica r: 64 lines) and BEFORE this block looks at the totals
+            // of the groups before it: a total depends on its own group only, so all of them appear at about the same time
+            // (published after that look, they formed a chain, 0.85 us per group: 30 us at 1080p)
+            const uint32_t t = ok_group ? (uint32_t)in_group + n : kLookPoison;
+            __hip_atomic_store(&grp[(size_t)lane * ng + g], ((uint64_t)epoch << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (replica b % 64 of the totals, so that a total's readers are spread over 64 lines)
+        const uint64_t* my_grp = grp + (size_t)(b % kLookGroup) * ng;
+        for (uint32_t q = lane; q < g && ok_before; q += 64u) {
+            uint32_t v;
+            ok_before = look_wait(&my_grp[q], epoch, max_polls, v) && v != kLookPoison;
+            before += v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += __shfl_xor(before, d);
+        }
+        ok_before = __all(ok_before);
+        if (lane == 0u) {
+            *s_G = before + in_group;
+            *s_ok = (ok_group && ok_before) ? 1u : 0u;
+        }
+    }
+    __syncthreads();
+    return *s_ok != 0u;
+}
+
+// Bytes [0, n) of the LDS image `img` (16-byte aligned) to out[G, G + n): the image starts at offset 0 whatever G's phase, so a 16-byte
+// line of the destination is five aligned dwords of the image and a byte shift (four unaligned dword reads become an unaligned
+// ds_read_b128, which is slow: the one-launch form ran 45 us with them).  Head and tail of partial lines byte by byte.
+__device__ __forceinline__ void copy_out_image(const uint8_t* img, uint32_t n, uint64_t G, uint8_t* out)
+{
+    const uint32_t pad = (uint32_t)(G & 15u);
+    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
+    const uint32_t body16 = (n - head) / 16u;
+    const uint32_t tail = n - head - body16 * 16u;
+    if (threadIdx.x < head) {
+        out[G + threadIdx.x] = img[threadIdx.x];
+    }
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(img) + (head >> 2);
+    const uint32_t shift = head & 3u;
+    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
+    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
+        // (the fifth dword of the image's last line may lie past the image: read only what exists)
+        const uint32_t a0 = src32[4u * i], a1 = src32[4u * i + 1u], a2 = src32[4u * i + 2u], a3 = src32[4u * i + 3u];
+        const uint32_t a4 = shift != 0u ? src32[4u * i + 4u] : 0u;
+        uint4 v;
+        v.x = __builtin_amdgcn_alignbyte(a1, a0, shift);
+        v.y = __builtin_amdgcn_alignbyte(a2, a1, shift);
+        v.z = __builtin_amdgcn_alignbyte(a3, a2, shift);
+        v.w = __builtin_amdgcn_alignbyte(a4, a3, shift);
+        dst16[i] = v;
+    }
+    if (threadIdx.x < tail) {
+        out[G + head + body16 * 16u + threadIdx.x] = img[head + body16 * 16u + threadIdx.x];
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng,
                                                            uint32_t epoch, uint32_t max_polls, uint8_t* out, uint64_t* total_out, uint32_t lead)
@@ -712,85 +795,110 @@ __global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __res
         at += len[k];
     }
 
-    // the look-back, by the first wave
-    if (threadIdx.x < 64u) {
-        const uint32_t lane = threadIdx.x;
-        const uint32_t g = b / kLookGroup, first = g * kLookGroup;
-        uint64_t before = 0, in_group = 0;
-        bool ok_group = true, ok_before = true;
-        if (first + lane < b) {
-            uint32_t v;
-            ok_group = look_wait(&agg[first + lane], epoch, max_polls, v);
-            in_group = v;
-        }
-        if (max_polls == 0u && b % 3u == 1u) {
-            ok_group = false; // (tests: a launch whose blocks give up, RTX_OPT_MINIMIZE_FUSED = 2)
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            in_group += __shfl_xor(in_group, d);
-        }
-        ok_group = __all(ok_group);
-        if (b % kLookGroup == kLookGroup - 1u) {
-            // the group's total, once per replica (lane r writes replica r: 64 lines) and BEFORE this block looks at the totals
-            // of the groups before it: a total depends on its own group only, so all of them appear at about the same time
-            // (published after that look, they formed a chain, 0.85 us per group: 30 us at 1080p)
-            const uint32_t t = ok_group ? (uint32_t)in_group + n : kLookPoison;
-            __hip_atomic_store(&grp[(size_t)lane * ng + g], ((uint64_t)epoch << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (replica b % 64 of the totals, so that a total's readers are spread over 64 lines)
-        const uint64_t* my_grp = grp + (size_t)(b % kLookGroup) * ng;
-        for (uint32_t q = lane; q < g && ok_before; q += 64u) {
-            uint32_t v;
-            ok_before = look_wait(&my_grp[q], epoch, max_polls, v) && v != kLookPoison;
-            before += v;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            before += __shfl_xor(before, d);
-        }
-        ok_before = __all(ok_before);
-        if (lane == 0u) {
-            s_G = before + in_group;
-            s_ok = (ok_group && ok_before) ? 1u : 0u;
-        }
-    }
-    __syncthreads(); // the image is complete, the offset known
-    if (s_ok == 0u) {
+    if (!look_back(b, n, agg, grp, ng, epoch, max_polls, &s_G, &s_ok)) {
         if (threadIdx.x == 0) {
             total_out[1] = epoch; // the host runs the three-launch form over the same words
         }
         return;
     }
-    const uint64_t G = s_G;
-    // copy out: bytes [G, G + n); the LDS image starts at offset 0 whatever G's phase, so a 16-byte line of the destination is five
-    // aligned dwords of the image and a byte shift (four unaligned dword reads become an unaligned ds_read_b128, which is slow)
-    const uint32_t pad = (uint32_t)(G & 15u);
-    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
-    const uint32_t body16 = (n - head) / 16u;
-    const uint32_t tail = n - head - body16 * 16u;
-    if (threadIdx.x < head) {
-        out[G + threadIdx.x] = s_buf[threadIdx.x];
-    }
-    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(s_buf) + (head >> 2);
-    const uint32_t shift = head & 3u;
-    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
-    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
-        // (the fifth dword of the image's last line may lie past the image: read only what exists)
-        const uint32_t a0 = src32[4u * i], a1 = src32[4u * i + 1u], a2 = src32[4u * i + 2u], a3 = src32[4u * i + 3u];
-        const uint32_t a4 = shift != 0u ? src32[4u * i + 4u] : 0u;
-        uint4 v;
-        v.x = __builtin_amdgcn_alignbyte(a1, a0, shift);
-        v.y = __builtin_amdgcn_alignbyte(a2, a1, shift);
-        v.z = __builtin_amdgcn_alignbyte(a3, a2, shift);
-        v.w = __builtin_amdgcn_alignbyte(a4, a3, shift);
-        dst16[i] = v;
-    }
-    if (threadIdx.x < tail) {
-        out[G + head + body16 * 16u + threadIdx.x] = s_buf[head + body16 * 16u + threadIdx.x];
-    }
+    copy_out_image(s_buf, n, s_G, out);
     if (b == gridDim.x - 1u && threadIdx.x == 0) {
-        total_out[0] = G + n; // length of the minimised stream
+        total_out[0] = s_G + n; // length of the minimised stream
+    }
+}
+
+// The record form (rtx_min_count -> rtx_min_scatter above) as one launch, on the same look-back: a block owns 1024 consecutive slots,
+// a thread four of them; the records are staged in LDS, a thread takes its four into registers, the block counts and publishes, the
+// bytes it keeps go back into the same LDS (from offset 0: every record has been read by then), and the offset comes from the blocks
+// before it.  The records are read once (41.5 MB at 1080p RGB) where the two launches read them twice.
+constexpr int kRSlotsPerBlock = kThreads * 4;
+
+template <int S>
+__device__ __forceinline__ void stage_records(const uint8_t* __restrict__ in, uint64_t first_slot, uint64_t n_slots, uint8_t* s_in)
+{
+    const uint64_t b0 = first_slot * S;
+    const uint64_t total_bytes = n_slots * S;
+    const uint64_t b1 = b0 + (uint64_t)kRSlotsPerBlock * S < total_bytes ? b0 + (uint64_t)kRSlotsPerBlock * S : total_bytes;
+    const uint32_t nbytes = (uint32_t)(b1 - b0); // multiple of 4; in + b0 is 16-byte aligned (1024 S is a multiple of 16)
+    const uint32_t n16 = nbytes / 16u;
+    const uint4* src = reinterpret_cast<const uint4*>(in + b0);
+    uint4* dst = reinterpret_cast<uint4*>(s_in + kHaloOff);
+    for (uint32_t i = threadIdx.x; i < n16; i += kThreads) {
+        dst[i] = src[i];
+    }
+    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(in + b0);
+    uint32_t* dst32 = reinterpret_cast<uint32_t*>(s_in + kHaloOff);
+    for (uint32_t i = n16 * 4u + threadIdx.x; i < nbytes / 4u; i += kThreads) {
+        dst32[i] = src32[i];
+    }
+    if (threadIdx.x < 2u * S / 4u) {
+        const uint32_t hd = threadIdx.x; // dword of the halo (the two slots before the block), counted from its start
+        uint32_t v = 0u;
+        if (b0 >= 2u * S) {
+            v = reinterpret_cast<const uint32_t*>(in + b0 - 2u * S)[hd];
+        } else if (b0 >= S && hd >= S / 4u) {
+            v = reinterpret_cast<const uint32_t*>(in + b0 - S)[hd - S / 4u];
+        }
+        reinterpret_cast<uint32_t*>(s_in + kHaloOff - 2 * S)[hd] = v;
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(kThreads) void rtx_min_fused(const uint8_t* in, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng, uint32_t epoch,
+                                                          uint32_t max_polls, uint8_t* out, uint64_t* total_out)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kRSlotsPerBlock * S];
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ uint64_t s_G;
+    __shared__ uint32_t s_ok;
+    const uint32_t b = blockIdx.x;
+    const uint64_t base = (uint64_t)b * kRSlotsPerBlock;
+    stage_records<S>(in, base, n_slots, s_in);
+    const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((base >> 32) == 0u ? (uint32_t)base % W : (uint32_t)(base % W));
+    uint32_t col = (col0 + threadIdx.x * 4u) % W;
+    __syncthreads();
+
+    Slot<S> rec[4];
+    uint32_t len[4], cols[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int li = (int)threadIdx.x * 4 + k;
+        const uint64_t g = base + (uint64_t)li;
+        len[k] = 0u;
+        cols[k] = col;
+        if (g < n_slots) {
+            len[k] = staged_length<S>(in, s_in, g, li, col, W, rec[k]);
+        }
+        mine += len[k];
+        col = col + 1u == W ? 0u : col + 1u;
+    }
+    uint32_t n;
+    uint32_t at = block_exclusive_scan(mine, s_wave, n); // (its barriers: every thread holds its records; s_in is free)
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&agg[b], ((uint64_t)epoch << 32) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint8_t* dst = s_in + at;
+        if (len[k] == (uint32_t)S) {
+#pragma unroll
+            for (int q = 0; q < S / 4; q++) {
+                *reinterpret_cast<u32_unaligned*>(dst + 4 * q) = rec[k].w[q];
+            }
+        } else if (len[k] == 1u) {
+            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (uint8_t)(rec[k].w[S / 4 - 1] >> 24);
+        }
+        at += len[k];
+    }
+    if (!look_back(b, n, agg, grp, ng, epoch, max_polls, &s_G, &s_ok)) {
+        if (threadIdx.x == 0) {
+            total_out[1] = epoch; // the host runs the two-launch form over the same records
+        }
+        return;
+    }
+    copy_out_image(s_in, n, s_G, out);
+    if (b == gridDim.x - 1u && threadIdx.x == 0) {
+        total_out[0] = s_G + n;
     }
 }
 
@@ -822,7 +930,7 @@ int ensure_min_buffers(rtx_ctx* ctx, size_t n_blocks, bool need_out)
     return RTX_OK;
 }
 
-int launch_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, uint64_t** d_total)
+int launch_minimize_chain(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, uint64_t** d_total)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const size_t n_blocks = (size_t)((n_slots + rtx::kSlotsPerBlock - 1) / rtx::kSlotsPerBlock);
@@ -902,6 +1010,56 @@ int ensure_look_tables(rtx_ctx* ctx, size_t n_blocks)
     }
     RTX_HIP(ctx, hipMemsetAsync(ctx->d_look, 0, bytes, ctx->stream));
     ctx->look_blocks = cap;
+    return RTX_OK;
+}
+
+// Minimize from the records of a W*H frame on the context's stream: one launch (rtx_min_fused, RTX_OPT_MINIMIZE_FUSED) or the two of
+// launch_minimize_chain.  As for the word form: (*d_total)[0] will hold the stream's length, and after a fused launch
+// (ctx->min_fused_epoch != 0) (*d_total)[1] == that epoch says that blocks gave up -- settle_minimize redoes the frame.
+int launch_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, uint64_t** d_total)
+{
+    const uint64_t n_slots = (uint64_t)w * h;
+    const uint64_t n_blocks = (n_slots + rtx::kRSlotsPerBlock - 1) / rtx::kRSlotsPerBlock;
+    ctx->min_fused_epoch = 0;
+    if (ctx->opt_min_fused == 0 || n_blocks > (1u << 24)) return launch_minimize_chain(ctx, d_scan, mode, w, h, d_in, d_out, d_total);
+    int rc = ensure_look_tables(ctx, (size_t)n_blocks);
+    if (rc != RTX_OK) return rc;
+    if (++ctx->look_epoch == 0u) {
+        RTX_HIP(ctx, hipMemsetAsync(ctx->d_look, 0, 2 * ctx->look_blocks * sizeof(uint64_t), ctx->stream));
+        ctx->look_epoch = 1u;
+    }
+    const uint32_t epoch = ctx->look_epoch;
+    uint64_t* total = (uint64_t*)d_scan;
+    uint64_t* agg = ctx->d_look;
+    uint64_t* grp = agg + ctx->look_blocks;
+    const uint32_t ng = (uint32_t)(ctx->look_blocks / rtx::kLookGroup);
+    const uint32_t polls = ctx->opt_min_fused == 2 ? 0u : rtx::kLookPolls;
+    const bool rgb = !(mode == RTX_BIT_ASCII || mode == RTX_BIT_PIXEL); // MinimizeResults, RayTracingManager.cu:167-179
+    if (rgb) {
+        hipLaunchKernelGGL((rtx::rtx_min_fused<20>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, ctx->stream, d_in, n_slots, (uint32_t)w, agg, grp, ng, epoch, polls, d_out,
+                           total);
+    } else {
+        hipLaunchKernelGGL((rtx::rtx_min_fused<12>), dim3((unsigned)n_blocks), dim3(rtx::kThreads), 0, ctx->stream, d_in, n_slots, (uint32_t)w, agg, grp, ng, epoch, polls, d_out,
+                           total);
+    }
+    RTX_HIP(ctx, hipGetLastError());
+    ctx->min_fused_epoch = epoch;
+    *d_total = total;
+    return RTX_OK;
+}
+
+int settle_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint8_t* d_in, uint8_t* d_out, const uint64_t got[2], uint64_t* total)
+{
+    *total = got[0];
+    const uint32_t epoch = ctx->min_fused_epoch;
+    ctx->min_fused_epoch = 0;
+    if (epoch == 0u || got[1] != (uint64_t)epoch) return RTX_OK;
+    ctx->stat_min_fallbacks++;
+    uint64_t* d_total = nullptr;
+    int rc = launch_minimize_chain(ctx, d_scan, mode, w, h, d_in, d_out, &d_total);
+    if (rc != RTX_OK) return rc;
+    RTX_HIP(ctx, hipMemcpyAsync(total, d_total, sizeof *total, hipMemcpyDeviceToHost, ctx->stream));
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RTX_OK;
 }
 
@@ -1176,9 +1334,10 @@ int rtx_minimize(rtx_ctx* ctx, int mode, size_t w, size_t h, const void* d_in, v
     uint64_t* d_total = nullptr;
     rc = launch_minimize(ctx, ctx->d_scan, mode, w, h, (const uint8_t*)d_in, (uint8_t*)d_out, &d_total);
     if (rc != RTX_OK) return rc;
-    uint64_t total = 0;
-    RTX_HIP(ctx, hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t got[2] = {0, 0}, total = 0;
+    RTX_HIP(ctx, hipMemcpyAsync(got, d_total, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
     RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = settle_minimize(ctx, ctx->d_scan, mode, w, h, (const uint8_t*)d_in, (uint8_t*)d_out, got, &total)) != RTX_OK) return rc;
     *out_bytes = (size_t)total;
     return RTX_OK;
 }
@@ -1355,9 +1514,14 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     // the length is needed on the host to size the copy: wait for this frame's kernels (the previous frame's
     // copy keeps running on the copy stream meanwhile)
     RTX_HIP(ctx, hipEventSynchronize(sl.ev_ready));
-    if (from_words) {
+    {
         uint64_t total = 0;
-        if ((rc = settle_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, sl.d_min, sl.h_total, &total)) != RTX_OK) return rc;
+        if (from_words) {
+            rc = settle_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, sl.d_min, sl.h_total, &total);
+        } else {
+            rc = settle_minimize(ctx, sl.d_scan, mode, w, h, sl.d_frame, sl.d_min, sl.h_total, &total);
+        }
+        if (rc != RTX_OK) return rc;
         sl.h_total[0] = total;
     }
     sl.bytes = (size_t)*sl.h_total;

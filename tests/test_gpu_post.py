@@ -596,3 +596,39 @@ def test_fused_minimize_beside_other_launches(R):
         torch.cuda.synchronize()
         assert O.fnv1a64(c.update(p2, R.RGB_ASCII)) == gold["minimized_fnv1a64"]
         assert c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 0
+
+
+# ---- the record form of Minimize as one launch (rtx_min_fused)
+
+@pytest.mark.parametrize("res", [(1024, 1), (1024, 64), (1024, 65), (1920, 1080), (977, 331), (5, 3), (1, 7)])
+def test_fused_record_minimize_is_the_two_launch_minimize(R, ctx, res):
+    """rtx_minimize (records in, RayTracingManager.cu:167-319) as one launch against the two launches (RTX_OPT_MINIMIZE_FUSED = 0) and,
+    for the smaller frames, the oracle: frames made of random words expanded to records (so that escapes are elided and slots are
+    empty), both record sizes; then with blocks that give up (2): the same bytes, the fallback counted."""
+    import torch
+    w, h = res
+    rng = np.random.default_rng(w * 31 + h)
+    for mode, holes in ((R.RGB_ASCII, 0.0), (R.BIT_PIXEL, 0.1), (R.RGB_PIXEL, 0.6)):
+        S = 20 if mode >= R.RGB_ASCII else 12
+        hw = U.random_words(rng, w, h, runs=0.6, holes=holes)
+        if mode < R.RGB_ASCII:
+            hw = np.where((hw != 0) & (hw != 0xFFFFFFFF), hw & np.uint32(0xFF0000FF), hw).astype(np.uint32)
+        frame = np.zeros(20 * w * h, dtype=np.uint8)
+        frame[:S * w * h] = U.words_to_records(hw, S, ord("3") if mode in (R.RGB_ASCII, R.BIT_ASCII) else ord("4"))
+        src = torch.from_numpy(frame).cuda()
+        out = {}
+        before = ctx.get_option(R.STAT_MINIMIZE_FALLBACKS)
+        for fused in (0, 1, 2):
+            ctx.set_option(R.OPT_MINIMIZE_FUSED, fused)
+            dst = torch.full((S * w * h + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            n = ctx.minimize(mode, w, h, src.data_ptr(), dst.data_ptr())
+            got = dst.cpu().numpy()
+            assert (got[n:] == 0xEE).all(), "bytes written past the stream"
+            out[fused] = got[:n].copy()
+        ctx.set_option(R.OPT_MINIMIZE_FUSED, -1)
+        assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2]), (res, R.MODE_NAMES[mode])
+        assert ctx.get_option(R.STAT_MINIMIZE_FALLBACKS) - before == (1 if w * h > 1024 else 0)
+        if w * h <= 1024 * 65:
+            want = O.minimize(mode, frame, w, h)
+            assert out[1].size == want.size and np.array_equal(out[1], want), (res, R.MODE_NAMES[mode])

@@ -11,898 +11,7 @@
 #include <cstring>
 #include <vector>
 
-namespace rtx {
-
-constexpr int kThreads = 256;
-constexpr int kItems = 2;                      // slots per thread
-constexpr int kSlotsPerBlock = kThreads * kItems;
-
-// ---------------------------------------------------------------- UpdateObjects
-// Sphere::Update, Sphere.cu:15-23 (long double is double in device code); Plane::Update is a no-op
-// (Plane.cu:14-18).  One thread per sphere with a launch shape that is valid for any count: the
-// reference's block of `count` threads stops launching past 1024 objects.
-__global__ __launch_bounds__(kThreads) void rtx_update_spheres(float4* geom, float4* motion, uint32_t ns, double dt, float4* sorted_geom,
-                                                               const uint32_t* pos_of)
-{
-    const uint32_t i = blockIdx.x * kThreads + threadIdx.x;
-    if (i >= ns) {
-        return;
-    }
-    float4 g = geom[i];
-    float4 mv = motion[i];
-    int mover = (int)__float_as_uint(mv.x);
-    const float speed = mv.y;
-    // m_center.y += speed * mover * dt;
-    g.y = (float)((double)g.y + (double)(speed * (float)mover) * dt);
-    if (g.y < -10.0f || g.y > 10.0f) {
-        const float r = g.y < -10.0f ? -10.0f : g.y; // MyMath::Clamp, MyMath.cu:29-34
-        g.y = r > 10.0f ? 10.0f : r;
-        mover *= -1;
-    }
-    mv.x = __uint_as_float((uint32_t)mover);
-    geom[i] = g;
-    motion[i] = mv;
-    if (sorted_geom != nullptr) {
-        sorted_geom[pos_of[i]] = g; // the direction-sorted copy staging reads (rtx_sort_scene) moves with it
-    }
-}
-
-// sorted[p] = geom[order[p]]: the direction-sorted copy of the sphere array, from the live one.
-__global__ __launch_bounds__(kThreads) void rtx_gather_spheres(const float4* geom, const float4* od, const uint32_t* order, float4* sorted_geom,
-                                                               float4* sorted_od, uint32_t ns)
-{
-    const uint32_t p = blockIdx.x * kThreads + threadIdx.x;
-    if (p < ns) {
-        sorted_geom[p] = geom[order[p]];
-        sorted_od[p] = od[order[p]];
-    }
-}
-
-// ---------------------------------------------------------------- ansi256_from_rgb over a range of inputs
-// The mapper of the 8-bit trace kernels (rtx_device.hpp, ANSIRGB.h:141-189) applied to packed 0xRRGGBB values
-// first .. first+count-1, four per thread, one dword store each.
-__global__ __launch_bounds__(kThreads) void rtx_ansi_map(uint32_t first, uint64_t count, const uint8_t* grey, uint8_t* out)
-{
-    const uint64_t i0 = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) * 4u;
-    if (i0 >= count) {
-        return;
-    }
-    uint32_t v[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) {
-        const uint32_t rgb = first + (uint32_t)i0 + k;
-        v[k] = ansi256_from_rgb((rgb >> 16) & 255u, (rgb >> 8) & 255u, rgb & 255u, grey);
-    }
-    if (i0 + 4u <= count && (((uintptr_t)(out + i0)) & 3u) == 0u) {
-        *reinterpret_cast<uint32_t*>(out + i0) = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-    } else {
-        for (uint32_t k = 0; k < 4u && i0 + k < count; k++) {
-            out[i0 + k] = (uint8_t)v[k];
-        }
-    }
-}
-
-// ---------------------------------------------------------------- Minimize
-//
-// The reference scans the frame byte by byte on one CPU thread.  Restated per slot (a slot is one
-// S-byte record position; W slots per row, the last one being the row's NUL column):
-//   * NUL-column slot           -> emits '\n'                        (RayTracingManager.cu:223-239)
-//   * slot starting with ESC    -> emits the whole record if its colour digits differ from the
-//                                  colour of the previous ESC slot in scan order (rows included),
-//                                  else only its last byte (the glyph)   (:193-220)
-//   * any other slot (all NUL)  -> emits nothing                     (:241-245)
-// "latestColor" only moves when the colour differs, so comparing with the previous ESC slot is the
-// same test.  Output offsets are an exclusive prefix sum of the emitted lengths.
-template <int S>
-struct Slot {
-    uint32_t w[S / 4];
-};
-
-template <int S>
-__device__ __forceinline__ bool same_colour(const Slot<S>& a, const Slot<S>& b)
-{
-    if (S == 12) {
-        // bytes 7, 8, 9
-        return ((a.w[1] ^ b.w[1]) & 0xff000000u) == 0u && ((a.w[2] ^ b.w[2]) & 0x0000ffffu) == 0u;
-    }
-    // bytes 7-9, 11-13, 15-17
-    return ((a.w[1] ^ b.w[1]) & 0xff000000u) == 0u && ((a.w[2] ^ b.w[2]) & 0xff00ffffu) == 0u &&
-           ((a.w[3] ^ b.w[3]) & 0xff00ffffu) == 0u && ((a.w[4] ^ b.w[4]) & 0x0000ffffu) == 0u;
-}
-
-template <int S>
-__device__ __forceinline__ Slot<S> load_slot(const uint8_t* in, uint64_t i)
-{
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(in + i * S);
-    Slot<S> s;
-#pragma unroll
-    for (int k = 0; k < S / 4; k++) {
-        s.w[k] = p[k];
-    }
-    return s;
-}
-
-// Emitted length of slot i; `rec` receives the record when the slot is a pixel.
-template <int S>
-__device__ __forceinline__ uint32_t slot_length(const uint8_t* in, uint64_t i, uint32_t W, Slot<S>& rec)
-{
-    const uint32_t col = (uint32_t)(i % W);
-    if (col == W - 1u) {
-        return 1u; // newline
-    }
-    rec = load_slot<S>(in, i);
-    if ((rec.w[0] & 0xffu) != 0x1bu) {
-        return 0u;
-    }
-    // previous ESC slot in scan order: for a rendered frame this is slot i-1, or i-2 across a row end
-    uint64_t j = i;
-    while (j > 0) {
-        --j;
-        if ((uint32_t)(j % W) == W - 1u) {
-            continue;
-        }
-        if (in[j * S] == 0x1bu) {
-            const Slot<S> prev = load_slot<S>(in, j);
-            return same_colour<S>(rec, prev) ? 1u : (uint32_t)S;
-        }
-    }
-    return (uint32_t)S; // first pixel of the frame
-}
-
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* s_wave, uint32_t& block_total)
-{
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= (uint32_t)d) {
-            incl += o;
-        }
-    }
-    if (lane == 63u) {
-        s_wave[wave] = incl;
-    }
-    __syncthreads();
-    uint32_t base = 0, total = 0;
-#pragma unroll
-    for (int k = 0; k < kThreads / 64; k++) {
-        const uint32_t t = s_wave[k];
-        base += (uint32_t)k < wave ? t : 0u;
-        total += t;
-    }
-    __syncthreads();
-    block_total = total;
-    return base + incl - v;
-}
-
-// ---- staged form.  A block owns kSlotsPerBlock consecutive slots.  Its input bytes (plus a halo of the two
-// slots before it, which is where the previous ESC slot of a rendered frame always is) are brought into
-// LDS with coalesced 16-byte loads; slots are then read from LDS at their 12/20-byte stride (5 or 3 dwords:
-// odd strides are bank-conflict free).  The scatter kernel also builds its output bytes in LDS and writes
-// them out with aligned 16-byte stores, so that HBM sees only full-width traffic.
-constexpr int kHaloOff = 48; // LDS byte offset of the block's first slot: 16-byte aligned, room for 2 x 20 halo bytes
-
-template <int S>
-__device__ __forceinline__ void stage_input(const uint8_t* __restrict__ in, uint64_t first_slot, uint64_t n_slots, uint8_t* s_in)
-{
-    const uint64_t b0 = first_slot * S;
-    const uint64_t total_bytes = n_slots * S;
-    const uint64_t b1 = b0 + (uint64_t)kSlotsPerBlock * S < total_bytes ? b0 + (uint64_t)kSlotsPerBlock * S : total_bytes;
-    const uint32_t nbytes = (uint32_t)(b1 - b0);           // multiple of 4
-    const uint32_t n16 = nbytes / 16u;
-    const uint4* src = reinterpret_cast<const uint4*>(in + b0);
-    uint4* dst = reinterpret_cast<uint4*>(s_in + kHaloOff);
-    for (uint32_t i = threadIdx.x; i < n16; i += kThreads) {
-        dst[i] = src[i];
-    }
-    // tail dwords (when the frame ends inside this block) and the halo
-    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(in + b0);
-    uint32_t* dst32 = reinterpret_cast<uint32_t*>(s_in + kHaloOff);
-    for (uint32_t i = n16 * 4u + threadIdx.x; i < nbytes / 4u; i += kThreads) {
-        dst32[i] = src32[i];
-    }
-    if (threadIdx.x < 2u * S / 4u) {
-        const uint32_t hd = threadIdx.x; // dword of the halo, counted from its start
-        uint32_t v = 0u;
-        if (b0 >= 2u * S) {
-            v = reinterpret_cast<const uint32_t*>(in + b0 - 2u * S)[hd];
-        } else if (b0 >= S && hd >= S / 4u) {
-            v = reinterpret_cast<const uint32_t*>(in + b0 - S)[hd - S / 4u];
-        }
-        reinterpret_cast<uint32_t*>(s_in + kHaloOff - 2 * S)[hd] = v;
-    }
-}
-
-template <int S>
-__device__ __forceinline__ Slot<S> lds_slot(const uint8_t* s_in, int li)
-{
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(s_in + kHaloOff + li * S);
-    Slot<S> r;
-#pragma unroll
-    for (int k = 0; k < S / 4; k++) {
-        r.w[k] = p[k];
-    }
-    return r;
-}
-
-// Emitted length of global slot g = first_slot + li, whose bytes (and halo) are staged in LDS.
-template <int S>
-__device__ __forceinline__ uint32_t staged_length(const uint8_t* in, const uint8_t* s_in, uint64_t g, int li, uint32_t col, uint32_t W, Slot<S>& rec)
-{
-    if (col == W - 1u) {
-        return 1u; // newline
-    }
-    rec = lds_slot<S>(s_in, li);
-    if ((rec.w[0] & 0xffu) != 0x1bu) {
-        return 0u;
-    }
-    if (g == 0) {
-        return (uint32_t)S; // first pixel of the frame
-    }
-    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's NUL column
-    const int back = col == 0u ? 2 : 1;
-    if (g >= (uint64_t)back) {
-        const Slot<S> prev = lds_slot<S>(s_in, li - back);
-        if ((prev.w[0] & 0xffu) == 0x1bu) {
-            return same_colour<S>(rec, prev) ? 1u : (uint32_t)S;
-        }
-    }
-    // not a fully rendered frame (empty slots in between): walk back through global memory
-    uint64_t j = g;
-    while (j > 0) {
-        --j;
-        if ((uint32_t)(j % W) == W - 1u) {
-            continue;
-        }
-        if (in[j * S] == 0x1bu) {
-            const Slot<S> prev = load_slot<S>(in, j);
-            return same_colour<S>(rec, prev) ? 1u : (uint32_t)S;
-        }
-    }
-    return (uint32_t)S;
-}
-
-template <int S>
-__global__ __launch_bounds__(kThreads) void rtx_min_count(const uint8_t* in, uint64_t n_slots, uint32_t W, uint32_t* block_sums)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kSlotsPerBlock * S];
-    __shared__ uint32_t s_wave[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kSlotsPerBlock;
-    stage_input<S>(in, base, n_slots, s_in);
-    const uint32_t col0 = (uint32_t)(base % W); // one 64-bit division per thread; columns below are 32-bit
-    __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
-    for (int it = 0; it < kItems; it++) {
-        const int li = it * kThreads + (int)threadIdx.x;
-        const uint64_t g = base + (uint64_t)li;
-        if (g < n_slots) {
-            Slot<S> rec;
-            sum += staged_length<S>(in, s_in, g, li, (col0 + (uint32_t)li) % W, W, rec);
-        }
-    }
-    uint32_t total;
-    block_exclusive_scan(sum, s_wave, total);
-    if (threadIdx.x == 0) {
-        block_sums[blockIdx.x] = total;
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(kThreads) void rtx_min_scatter(const uint8_t* in, uint64_t n_slots, uint32_t W, const uint32_t* block_sums, uint8_t* out, uint64_t* total_out)
-{
-    __shared__ uint64_t s_part[kThreads / 64];
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kSlotsPerBlock * S];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 + kSlotsPerBlock * S];
-    __shared__ uint32_t s_wave[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kSlotsPerBlock;
-    stage_input<S>(in, base, n_slots, s_in);
-    // where this block's output starts: the sum of the lengths of the blocks before it (a few KB of L2 reads
-    // per block; cheaper than a separate scan launch)
-    uint64_t part = 0;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kThreads) {
-        part += block_sums[i];
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        part += __shfl_xor(part, d);
-    }
-    if ((threadIdx.x & 63u) == 0u) {
-        s_part[threadIdx.x >> 6] = part;
-    }
-    __syncthreads();
-    uint64_t G = 0;
-#pragma unroll
-    for (int k = 0; k < kThreads / 64; k++) {
-        G += s_part[k];
-    }
-    const uint32_t pad = (uint32_t)(G & 15u);     // the LDS image is laid out with the same 16-byte phase
-    const uint32_t col0 = (uint32_t)(base % W);
-    __syncthreads();
-
-    uint32_t carry = 0;
-#pragma unroll 1
-    for (int it = 0; it < kItems; it++) {
-        const int li = it * kThreads + (int)threadIdx.x;
-        const uint64_t g = base + (uint64_t)li;
-        Slot<S> rec;
-        uint32_t len = 0;
-        const uint32_t col = (col0 + (uint32_t)li) % W;
-        if (g < n_slots) {
-            len = staged_length<S>(in, s_in, g, li, col, W, rec);
-        }
-        uint32_t total;
-        const uint32_t excl = block_exclusive_scan(len, s_wave, total);
-        uint8_t* dst = s_out + pad + carry + excl;
-        if (len == (uint32_t)S) {
-#pragma unroll
-            for (int k = 0; k < S / 4; k++) {
-                const uint32_t w = rec.w[k];
-                dst[4 * k + 0] = (uint8_t)(w);
-                dst[4 * k + 1] = (uint8_t)(w >> 8);
-                dst[4 * k + 2] = (uint8_t)(w >> 16);
-                dst[4 * k + 3] = (uint8_t)(w >> 24);
-            }
-        } else if (len == 1u) {
-            const bool newline = col == W - 1u;
-            dst[0] = newline ? (uint8_t)'\n' : (uint8_t)(rec.w[S / 4 - 1] >> 24);
-        }
-        carry += total;
-    }
-    __syncthreads();
-
-    // copy out: bytes [G, G + carry).  Head up to the first 16-byte boundary and tail after the last one go
-    // out byte by byte (neighbouring blocks own the other bytes of those 16-byte lines); the body as uint4.
-    const uint32_t n = carry;
-    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
-    const uint32_t body16 = (n - head) / 16u;
-    const uint32_t tail = n - head - body16 * 16u;
-    if (threadIdx.x < head) {
-        out[G + threadIdx.x] = s_out[pad + threadIdx.x];
-    }
-    const uint4* src = reinterpret_cast<const uint4*>(s_out + pad + head); // pad + head is 0 mod 16
-    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
-    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
-        dst16[i] = src[i];
-    }
-    if (threadIdx.x < tail) {
-        out[G + head + body16 * 16u + threadIdx.x] = s_out[pad + head + body16 * 16u + threadIdx.x];
-    }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-        *total_out = G + n; // length of the minimised stream
-    }
-}
-
-// ---------------------------------------------------------------- Minimize from compact pixel words
-//
-// The same pass over the 4-byte pixel words the trace kernels can store instead of records (RTX_RENDER_COMPACT, rtx.h): a word
-// carries everything its record is made of, so the pass reads 4 bytes per pixel where the record form reads 12 or 20 -- twice.
-// rtx_update traces words and minimises from them: 8.3 MB written and 2 x 8.3 MB read per 1080p frame instead of 41.5 MB and
-// 2 x 41.5 MB (the full-size records never exist), and a device group gathers the words it minimises from (no expansion).
-// Slot rules as above, stated on words:
-//   * column W-1                          -> '\n'
-//   * word 0xffffffff elsewhere           -> an empty slot (all NUL as a record): emits nothing, is not an ESC slot
-//   * any other word (0 = miss)           -> an ESC slot: its record is record_words<MODE>(word); the colour Minimize compares
-//     (bytes 7-9 [, 11-13, 15-17] of the record: the decimal digits) is a function of the word's colour bytes alone -- the
-//     digits of (r, g, b) or of the xterm index; a miss carries the digits of (0, 0, 0) resp. of index 16 (App. B) -- so
-//     "same colour digits" is "same colour key".
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-constexpr int kWPerThread = 4;
-constexpr int kWSlotsPerBlock = kThreads * kWPerThread; // 1024 slots = 4 KB of words per block
-constexpr uint32_t kNoWord = 0xffffffffu;               // = kCompactNewline
-
-template <int MODE>
-__device__ __forceinline__ uint32_t colour_key(uint32_t w)
-{
-    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
-    return kRgb ? (w & 0x00ffffffu) : (w != 0u ? (w & 0xffu) : 16u);
-}
-
-// s_w[0..1] = the two words before the block's first slot (kNoWord where the frame begins), s_w[2 + li] = word of slot base + li
-// `lead`: how many words BEFORE words[0] exist and belong to the same frame (0, or the W words of the row above a slab: a rank of
-// a device group minimises its own rows and needs the last pixel of the row before them; rtx_update on a group, RTX_OPT_GROUP_UPDATE)
-__device__ __forceinline__ void stage_words(const uint32_t* __restrict__ words, uint64_t base, uint64_t n_slots, uint32_t* s_w, uint32_t lead)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint64_t g0 = base + (uint64_t)tid * kWPerThread;
-    if (g0 + kWPerThread <= n_slots && ((uintptr_t)(words + g0) & 15u) == 0u) {
-        const uint4 v = *reinterpret_cast<const uint4*>(words + g0);
-        s_w[2 + tid * kWPerThread + 0] = v.x;
-        s_w[2 + tid * kWPerThread + 1] = v.y;
-        s_w[2 + tid * kWPerThread + 2] = v.z;
-        s_w[2 + tid * kWPerThread + 3] = v.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < kWPerThread; k++) {
-            s_w[2 + tid * kWPerThread + k] = g0 + k < n_slots ? words[g0 + k] : kNoWord;
-        }
-    }
-    if (tid < 2u) {
-        s_w[tid] = base + tid + lead >= 2u ? words[(int64_t)(base + tid) - 2] : kNoWord;
-    }
-}
-
-// Column of this thread's first slot: the block's first column by one scalar 64-bit division (the block index is uniform), the
-// thread's by a 32-bit one (a 64-bit division per thread is ~100 instructions, a third of what this pass executes).
-__device__ __forceinline__ uint32_t first_column(uint64_t base, uint32_t W)
-{
-    // (a 64-bit remainder is ~130 instructions, a tenth of what a wave of the one-launch form executes: 32-bit where the slot fits)
-    const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((base >> 32) == 0u ? (uint32_t)base % W : (uint32_t)(base % W));
-    return (col0 + threadIdx.x * (uint32_t)kWPerThread) % W; // (col0 < W < 2^31 and the offset < 1024: no overflow)
-}
-
-// The previous ESC slot of slot g is not among the two staged before it (a frame that was only partly rendered: empty slots in
-// between): walk back through global memory.  Rare, and kept out of line so that the passes' straight-line code stays short.
-template <int MODE>
-__device__ __noinline__ uint32_t word_length_walk(const uint32_t* __restrict__ words, uint64_t g, uint32_t W, uint32_t w, uint32_t lead)
-{
-    constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
-    int64_t j = (int64_t)g;
-    while (j > -(int64_t)lead) {
-        --j;
-        if ((uint32_t)((uint64_t)(j + (int64_t)lead) % W) == W - 1u) { // (lead is a multiple of W)
-            continue;
-        }
-        const uint32_t pw = words[j];
-        if (pw != kNoWord) {
-            return colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
-        }
-    }
-    return S;
-}
-
-// Emitted length of slot g (column col, staged at s_w[2 + li]); `w` receives its word.  Selects, and one branch for the rare walk.
-template <int MODE>
-__device__ __forceinline__ uint32_t word_length(const uint32_t* __restrict__ words, const uint32_t* s_w, uint64_t g, int li, uint32_t col, uint32_t W, uint32_t& w,
-                                                uint32_t lead)
-{
-    constexpr uint32_t S = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS) ? 20u : 12u;
-    w = s_w[2 + li];
-    // previous ESC slot: slot g-1, or g-2 when g-1 is the previous row's last column (both staged: s_w[0..1] precede the block)
-    const int back = col == 0u ? 2 : 1;
-    const uint32_t pw = s_w[2 + li - back];
-    const bool newline = col == W - 1u, empty = w == kNoWord, first = g == 0 && lead == 0u;
-    const bool staged = g + lead >= (uint64_t)back && pw != kNoWord;
-    uint32_t len = colour_key<MODE>(pw) == colour_key<MODE>(w) ? 1u : S;
-    len = first ? S : len;     // first pixel of the frame
-    len = empty ? 0u : len;    // empty slot
-    len = newline ? 1u : len;
-    if (!newline && !empty && !first && !staged) {
-        len = word_length_walk<MODE>(words, g, W, w, lead);
-    }
-    return len;
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void rtx_minw_count(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint32_t* block_sums, uint32_t lead)
-{
-    __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
-    __shared__ uint32_t s_wave[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
-    stage_words(words, base, n_slots, s_w, lead);
-    uint32_t col = first_column(base, W);
-    __syncthreads();
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < kWPerThread; k++) {
-        const int li = (int)threadIdx.x * kWPerThread + k;
-        const uint64_t g = base + (uint64_t)li;
-        uint32_t w;
-        if (g < n_slots) {
-            sum += word_length<MODE>(words, s_w, g, li, col, W, w, lead);
-        }
-        col = col + 1u == W ? 0u : col + 1u;
-    }
-    uint32_t total;
-    block_exclusive_scan(sum, s_wave, total);
-    if (threadIdx.x == 0) {
-        block_sums[blockIdx.x] = total;
-    }
-}
-
-// The blocks' sums -> their offsets in the stream (exclusive scan; one workgroup, 2048 sums per step) and the stream's length.
-// A launch of its own between the two passes: the scatter pass then finds its place with one load, where summing the preceding
-// blocks' sums in every block cost a chain of dependent L2 round trips per block and O(blocks^2) loads per frame (32 400 blocks
-// at 8K).  (Letting the count pass's last block do this -- a ticket drawn with atomicAdd -- was measured: 2025 device-scope
-// atomics on one address take 46 us, 22 ns each.)
-__global__ __launch_bounds__(kThreads) void rtx_min_offsets(const uint32_t* __restrict__ block_sums, uint32_t nb, uint64_t* __restrict__ offsets, uint64_t* total_out)
-{
-    __shared__ uint32_t s_wave[kThreads / 64];
-    uint64_t carry = 0;
-    for (uint32_t b0 = 0; b0 < nb; b0 += 8u * kThreads) {
-        uint32_t v[8], mine = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; q++) {
-            const uint32_t i = b0 + threadIdx.x * 8u + q;
-            v[q] = i < nb ? block_sums[i] : 0u;
-            mine += v[q];
-        }
-        uint32_t step_total;
-        uint64_t at = carry + block_exclusive_scan(mine, s_wave, step_total);
-#pragma unroll
-        for (uint32_t q = 0; q < 8u; q++) {
-            const uint32_t i = b0 + threadIdx.x * 8u + q;
-            if (i < nb) offsets[i] = at;
-            at += v[q];
-        }
-        carry += step_total;
-    }
-    if (threadIdx.x == 0) {
-        *total_out = carry; // length of the minimised stream
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void rtx_minw_scatter(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, const uint64_t* __restrict__ offsets,
-                                                             uint8_t* out, uint32_t lead)
-{
-    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
-    constexpr uint32_t S = kRgb ? 20u : 12u;
-    __shared__ uint32_t s_w[2 + kWSlotsPerBlock];
-    __shared__ uint32_t s_digits[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[16 + kWSlotsPerBlock * S];
-    __shared__ uint32_t s_wave[kThreads / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * kWSlotsPerBlock;
-    const uint64_t G = offsets[blockIdx.x]; // where this block's output starts (the count pass's last block left it)
-    stage_words(words, base, n_slots, s_w, lead);
-    s_digits[threadIdx.x] = digits_word(threadIdx.x);
-    uint32_t col = first_column(base, W);
-    __syncthreads();
-    const uint32_t pad = (uint32_t)(G & 15u); // the LDS image is laid out with the same 16-byte phase as its destination
-
-    uint32_t len[kWPerThread], wd[kWPerThread], cols[kWPerThread], mine = 0;
-#pragma unroll
-    for (int k = 0; k < kWPerThread; k++) {
-        const int li = (int)threadIdx.x * kWPerThread + k;
-        const uint64_t g = base + (uint64_t)li;
-        len[k] = 0u;
-        wd[k] = kNoWord;
-        cols[k] = col;
-        if (g < n_slots) {
-            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k], lead);
-        }
-        mine += len[k];
-        col = col + 1u == W ? 0u : col + 1u;
-    }
-    uint32_t n;
-    uint32_t at = pad + block_exclusive_scan(mine, s_wave, n);
-#pragma unroll
-    for (int k = 0; k < kWPerThread; k++) {
-        uint8_t* dst = s_out + at;
-        if (len[k] == S) {
-            Fields f;
-            f.c0 = wd[k] & 255u;
-            f.c1 = (wd[k] >> 8) & 255u;
-            f.c2 = (wd[k] >> 16) & 255u;
-            f.glyph = wd[k] >> 24;
-            uint32_t r[S / 4];
-            record_words<MODE>(wd[k] != kCompactMiss, f, s_digits, r);
-            // the record lands at an arbitrary byte offset of the LDS image: dword stores without an alignment promise (gfx950
-            // takes unaligned LDS accesses: one ds_write_b32 each, where byte stores were twenty)
-#pragma unroll
-            for (uint32_t q = 0; q < S / 4u; q++) {
-                *reinterpret_cast<u32_unaligned*>(dst + 4u * q) = r[q];
-            }
-        } else if (len[k] == 1u) {
-            // the row's newline, or the glyph alone (the last byte of the record: ' ' for a miss)
-            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (wd[k] == kCompactMiss ? (uint8_t)' ' : (uint8_t)(wd[k] >> 24));
-        }
-        at += len[k];
-    }
-    __syncthreads();
-
-    // copy out: bytes [G, G + n), head and tail of partial 16-byte lines byte by byte, the body as uint4
-    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
-    const uint32_t body16 = (n - head) / 16u;
-    const uint32_t tail = n - head - body16 * 16u;
-    if (threadIdx.x < head) {
-        out[G + threadIdx.x] = s_out[pad + threadIdx.x];
-    }
-    const uint4* src = reinterpret_cast<const uint4*>(s_out + pad + head); // pad + head is 0 mod 16
-    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
-    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
-        dst16[i] = src[i];
-    }
-    if (threadIdx.x < tail) {
-        out[G + head + body16 * 16u + threadIdx.x] = s_out[pad + head + body16 * 16u + threadIdx.x];
-    }
-}
-
-// ---- the same pass as ONE launch (rtx_minw_fused): count, offsets and scatter of the three launches above in one kernel, the
-// block offsets by a two-level look-back.  Three dependent launches of a few microseconds each pay two launch gaps and read the
-// words twice; here a block counts its slots, publishes its length, builds its output bytes in LDS while the other blocks do the
-// same, and then finds where its bytes go:
-//   * agg[b]  = (epoch << 32) | length of block b            published by every block as soon as it has counted
-//   * grp[r][g] = (epoch << 32) | length of blocks 64g..64g+63  published by the LAST block of the group, which reads the other 63
-//     lengths for its own offset anyway; 64 replicas r (rows of `ng` entries), block b reads replica b % 64
-//   * offset of block b = sum of grp[b % 64][0 .. b/64) + sum of agg[64 (b/64) .. b): one wave, one or a few loads per lane, two
-//     dependent steps for every block however many blocks there are (no chain of prefixes from block to block).
-// A block waits only for blocks with smaller indices; workgroups are dispatched in index order on every XCD, so the unfinished
-// block with the smallest index never waits and the launch drains.  All the same nothing here spins without a bound: a lane that
-// has polled max_polls times gives up, the block writes the launch's epoch into the failure word and stores nothing, a group's
-// last block that gave up publishes a poisoned total (the later blocks then give up at once), and the host runs the three
-// launches above instead (launch_minimize_words, settle_minimize_words).  Entries carry the launch's epoch, so the tables are
-// never cleared between launches; they are zeroed when allocated and epoch 0 is never used.
-constexpr uint32_t kLookGroup = 64u;
-constexpr uint32_t kLookPoison = 0xffffffffu;
-constexpr uint32_t kLookPolls = 1u << 18; // x >= 0.5 us per poll: at least a tenth of a second
-
-__device__ __forceinline__ bool look_wait(const uint64_t* p, uint32_t epoch, uint32_t max_polls, uint32_t& value)
-{
-    for (uint32_t i = 0;; i++) {
-        const uint64_t e = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(e >> 32) == epoch) {
-            value = (uint32_t)e;
-            return true;
-        }
-        if (i >= max_polls) {
-            value = 0u;
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// The look-back of block b, whose length n is already published in agg[b]: done by the first wave, the block's offset in *s_G and
-// the verdict in *s_ok (both in LDS), a barrier, and the verdict returned to every thread.  The barrier also completes whatever the
-// block wrote to LDS before the call (its output image).
-__device__ __forceinline__ bool look_back(uint32_t b, uint32_t n, const uint64_t* agg, uint64_t* grp, uint32_t ng, uint32_t epoch, uint32_t max_polls, uint64_t* s_G,
-                                          uint32_t* s_ok)
-{
-    if (threadIdx.x < 64u) {
-        const uint32_t lane = threadIdx.x;
-        const uint32_t g = b / kLookGroup, first = g * kLookGroup;
-        uint64_t before = 0, in_group = 0;
-        bool ok_group = true, ok_before = true;
-        if (first + lane < b) {
-            uint32_t v;
-            ok_group = look_wait(&agg[first + lane], epoch, max_polls, v);
-            in_group = v;
-        }
-        if (max_polls == 0u && b % 3u == 1u) {
-            ok_group = false; // (tests: a launch whose blocks give up, RTX_OPT_MINIMIZE_FUSED = 2)
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            in_group += __shfl_xor(in_group, d);
-        }
-        ok_group = __all(ok_group);
-        if (b % kLookGroup == kLookGroup - 1u) {
-            // the group's total, once per replica (lane r writes replica r: 64 lines) and BEFORE this block looks at the totals
-            // of the groups before it: a total depends on its own group only, so all of them appear at about the same time
-            // (published after that look, they formed a chain, 0.85 us per group: 30 us at 1080p)
-            const uint32_t t = ok_group ? (uint32_t)in_group + n : kLookPoison;
-            __hip_atomic_store(&grp[(size_t)lane * ng + g], ((uint64_t)epoch << 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // (replica b % 64 of the totals, so that a total's readers are spread over 64 lines)
-        const uint64_t* my_grp = grp + (size_t)(b % kLookGroup) * ng;
-        for (uint32_t q = lane; q < g && ok_before; q += 64u) {
-            uint32_t v;
-            ok_before = look_wait(&my_grp[q], epoch, max_polls, v) && v != kLookPoison;
-            before += v;
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            before += __shfl_xor(before, d);
-        }
-        ok_before = __all(ok_before);
-        if (lane == 0u) {
-            *s_G = before + in_group;
-            *s_ok = (ok_group && ok_before) ? 1u : 0u;
-        }
-    }
-    __syncthreads();
-    return *s_ok != 0u;
-}
-
-// Bytes [0, n) of the LDS image `img` (16-byte aligned) to out[G, G + n): the image starts at offset 0 whatever G's phase, so a 16-byte
-// line of the destination is five aligned dwords of the image and a byte shift (four unaligned dword reads become an unaligned
-// ds_read_b128, which is slow: the one-launch form ran 45 us with them).  Head and tail of partial lines byte by byte.
-__device__ __forceinline__ void copy_out_image(const uint8_t* img, uint32_t n, uint64_t G, uint8_t* out)
-{
-    const uint32_t pad = (uint32_t)(G & 15u);
-    const uint32_t head = n < ((16u - pad) & 15u) ? n : ((16u - pad) & 15u);
-    const uint32_t body16 = (n - head) / 16u;
-    const uint32_t tail = n - head - body16 * 16u;
-    if (threadIdx.x < head) {
-        out[G + threadIdx.x] = img[threadIdx.x];
-    }
-    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(img) + (head >> 2);
-    const uint32_t shift = head & 3u;
-    uint4* dst16 = reinterpret_cast<uint4*>(out + G + head);
-    for (uint32_t i = threadIdx.x; i < body16; i += kThreads) {
-        // (the fifth dword of the image's last line may lie past the image: read only what exists)
-        const uint32_t a0 = src32[4u * i], a1 = src32[4u * i + 1u], a2 = src32[4u * i + 2u], a3 = src32[4u * i + 3u];
-        const uint32_t a4 = shift != 0u ? src32[4u * i + 4u] : 0u;
-        uint4 v;
-        v.x = __builtin_amdgcn_alignbyte(a1, a0, shift);
-        v.y = __builtin_amdgcn_alignbyte(a2, a1, shift);
-        v.z = __builtin_amdgcn_alignbyte(a3, a2, shift);
-        v.w = __builtin_amdgcn_alignbyte(a4, a3, shift);
-        dst16[i] = v;
-    }
-    if (threadIdx.x < tail) {
-        out[G + head + body16 * 16u + threadIdx.x] = img[head + body16 * 16u + threadIdx.x];
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void rtx_minw_fused(const uint32_t* __restrict__ words, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng,
-                                                           uint32_t epoch, uint32_t max_polls, uint8_t* out, uint64_t* total_out, uint32_t lead)
-{
-    constexpr bool kRgb = (MODE == RTX_K_RGB_ASCII || MODE == RTX_K_RGB_PIXEL || MODE == RTX_K_RGB_NORMALS);
-    constexpr uint32_t S = kRgb ? 20u : 12u;
-    // the words first (2 + 1024 dwords) and the scan's partial sums behind them, then -- once every thread has its lengths -- the
-    // output bytes from offset 0, at most 1024 x S of them.  (What bounds this launch is the order its dependency imposes on the whole
-    // GPU -- every block reads and counts, then every block waits two memory round trips, then every block writes: per-block
-    // time stamps of a 1080p frame show lengths published at 2-4 us, offsets known at 6-8, the last byte written at 12.7 -- not the
-    // number of resident blocks or of instructions: a build with 20 480 bytes of LDS, eight blocks per CU and all 2025 blocks in
-    // one dispatch round was no faster, nor was halving the instructions of the length pass.  EXPERIMENTS.md R4.5.)
-    __shared__ __attribute__((aligned(16))) uint8_t s_buf[kWSlotsPerBlock * S];
-    __shared__ uint32_t s_digits[256];
-    __shared__ uint64_t s_G;
-    __shared__ uint32_t s_ok;
-    static_assert(sizeof(s_buf) >= (2 + kWSlotsPerBlock) * 4 + 8 + (kThreads / 64) * 4, "words + partial sums fit the image's space");
-    uint32_t* s_w = reinterpret_cast<uint32_t*>(s_buf);
-    uint32_t* s_wave = s_w + 2 + kWSlotsPerBlock + 2;
-    const uint32_t b = blockIdx.x;
-    const uint64_t base = (uint64_t)b * kWSlotsPerBlock;
-    stage_words(words, base, n_slots, s_w, lead);
-    s_digits[threadIdx.x] = digits_word(threadIdx.x);
-    uint32_t col = first_column(base, W);
-    __syncthreads();
-
-    uint32_t len[kWPerThread], wd[kWPerThread], cols[kWPerThread], mine = 0;
-#pragma unroll
-    for (int k = 0; k < kWPerThread; k++) {
-        const int li = (int)threadIdx.x * kWPerThread + k;
-        const uint64_t g = base + (uint64_t)li;
-        len[k] = 0u;
-        wd[k] = kNoWord;
-        cols[k] = col;
-        if (g < n_slots) {
-            len[k] = word_length<MODE>(words, s_w, g, li, col, W, wd[k], lead);
-        }
-        mine += len[k];
-        col = col + 1u == W ? 0u : col + 1u;
-    }
-    uint32_t n;
-    uint32_t at = block_exclusive_scan(mine, s_wave, n); // (its barriers: every thread has read its words and the sums; s_buf is free)
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&agg[b], ((uint64_t)epoch << 32) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-
-    // the output bytes, built while the other blocks publish their lengths
-#pragma unroll
-    for (int k = 0; k < kWPerThread; k++) {
-        uint8_t* dst = s_buf + at;
-        if (len[k] == S) {
-            Fields f;
-            f.c0 = wd[k] & 255u;
-            f.c1 = (wd[k] >> 8) & 255u;
-            f.c2 = (wd[k] >> 16) & 255u;
-            f.glyph = wd[k] >> 24;
-            uint32_t r[S / 4];
-            record_words<MODE>(wd[k] != kCompactMiss, f, s_digits, r);
-#pragma unroll
-            for (uint32_t q = 0; q < S / 4u; q++) {
-                *reinterpret_cast<u32_unaligned*>(dst + 4u * q) = r[q];
-            }
-        } else if (len[k] == 1u) {
-            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (wd[k] == kCompactMiss ? (uint8_t)' ' : (uint8_t)(wd[k] >> 24));
-        }
-        at += len[k];
-    }
-
-    if (!look_back(b, n, agg, grp, ng, epoch, max_polls, &s_G, &s_ok)) {
-        if (threadIdx.x == 0) {
-            total_out[1] = epoch; // the host runs the three-launch form over the same words
-        }
-        return;
-    }
-    copy_out_image(s_buf, n, s_G, out);
-    if (b == gridDim.x - 1u && threadIdx.x == 0) {
-        total_out[0] = s_G + n; // length of the minimised stream
-    }
-}
-
-// The record form (rtx_min_count -> rtx_min_scatter above) as one launch, on the same look-back: a block owns 1024 consecutive slots,
-// a thread four of them; the records are staged in LDS, a thread takes its four into registers, the block counts and publishes, the
-// bytes it keeps go back into the same LDS (from offset 0: every record has been read by then), and the offset comes from the blocks
-// before it.  The records are read once (41.5 MB at 1080p RGB) where the two launches read them twice.
-constexpr int kRSlotsPerBlock = kThreads * 4;
-
-template <int S>
-__device__ __forceinline__ void stage_records(const uint8_t* __restrict__ in, uint64_t first_slot, uint64_t n_slots, uint8_t* s_in)
-{
-    const uint64_t b0 = first_slot * S;
-    const uint64_t total_bytes = n_slots * S;
-    const uint64_t b1 = b0 + (uint64_t)kRSlotsPerBlock * S < total_bytes ? b0 + (uint64_t)kRSlotsPerBlock * S : total_bytes;
-    const uint32_t nbytes = (uint32_t)(b1 - b0); // multiple of 4; in + b0 is 16-byte aligned (1024 S is a multiple of 16)
-    const uint32_t n16 = nbytes / 16u;
-    const uint4* src = reinterpret_cast<const uint4*>(in + b0);
-    uint4* dst = reinterpret_cast<uint4*>(s_in + kHaloOff);
-    for (uint32_t i = threadIdx.x; i < n16; i += kThreads) {
-        dst[i] = src[i];
-    }
-    const uint32_t* src32 = reinterpret_cast<const uint32_t*>(in + b0);
-    uint32_t* dst32 = reinterpret_cast<uint32_t*>(s_in + kHaloOff);
-    for (uint32_t i = n16 * 4u + threadIdx.x; i < nbytes / 4u; i += kThreads) {
-        dst32[i] = src32[i];
-    }
-    if (threadIdx.x < 2u * S / 4u) {
-        const uint32_t hd = threadIdx.x; // dword of the halo (the two slots before the block), counted from its start
-        uint32_t v = 0u;
-        if (b0 >= 2u * S) {
-            v = reinterpret_cast<const uint32_t*>(in + b0 - 2u * S)[hd];
-        } else if (b0 >= S && hd >= S / 4u) {
-            v = reinterpret_cast<const uint32_t*>(in + b0 - S)[hd - S / 4u];
-        }
-        reinterpret_cast<uint32_t*>(s_in + kHaloOff - 2 * S)[hd] = v;
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(kThreads) void rtx_min_fused(const uint8_t* in, uint64_t n_slots, uint32_t W, uint64_t* agg, uint64_t* grp, uint32_t ng, uint32_t epoch,
-                                                          uint32_t max_polls, uint8_t* out, uint64_t* total_out)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[kHaloOff + kRSlotsPerBlock * S];
-    __shared__ uint32_t s_wave[kThreads / 64];
-    __shared__ uint64_t s_G;
-    __shared__ uint32_t s_ok;
-    const uint32_t b = blockIdx.x;
-    const uint64_t base = (uint64_t)b * kRSlotsPerBlock;
-    stage_records<S>(in, base, n_slots, s_in);
-    const uint32_t col0 = (uint32_t)__builtin_amdgcn_readfirstlane((base >> 32) == 0u ? (uint32_t)base % W : (uint32_t)(base % W));
-    uint32_t col = (col0 + threadIdx.x * 4u) % W;
-    __syncthreads();
-
-    Slot<S> rec[4];
-    uint32_t len[4], cols[4], mine = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int li = (int)threadIdx.x * 4 + k;
-        const uint64_t g = base + (uint64_t)li;
-        len[k] = 0u;
-        cols[k] = col;
-        if (g < n_slots) {
-            len[k] = staged_length<S>(in, s_in, g, li, col, W, rec[k]);
-        }
-        mine += len[k];
-        col = col + 1u == W ? 0u : col + 1u;
-    }
-    uint32_t n;
-    uint32_t at = block_exclusive_scan(mine, s_wave, n); // (its barriers: every thread holds its records; s_in is free)
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&agg[b], ((uint64_t)epoch << 32) | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint8_t* dst = s_in + at;
-        if (len[k] == (uint32_t)S) {
-#pragma unroll
-            for (int q = 0; q < S / 4; q++) {
-                *reinterpret_cast<u32_unaligned*>(dst + 4 * q) = rec[k].w[q];
-            }
-        } else if (len[k] == 1u) {
-            dst[0] = cols[k] == W - 1u ? (uint8_t)'\n' : (uint8_t)(rec[k].w[S / 4 - 1] >> 24);
-        }
-        at += len[k];
-    }
-    if (!look_back(b, n, agg, grp, ng, epoch, max_polls, &s_G, &s_ok)) {
-        if (threadIdx.x == 0) {
-            total_out[1] = epoch; // the host runs the two-launch form over the same records
-        }
-        return;
-    }
-    copy_out_image(s_in, n, s_G, out);
-    if (b == gridDim.x - 1u && threadIdx.x == 0) {
-        total_out[0] = s_G + n;
-    }
-}
-
-} // namespace rtx
+#include "rtx_post_kernels.inc" // namespace rtx: the kernels launched below
 
 namespace {
 

@@ -6,7 +6,7 @@ library), and -- `stamps` as first argument: experiment library -- what its work
 
   python tools/worst_view_gpu.py            # timings, product library
   python tools/worst_view_gpu.py stamps     # per-workgroup candidates and lifetimes, librtx_hip_ablate.so
-  --config=C5 (or C3 ...): another BASELINE scene; --coarse: every 0.2 rad
+  --config=C5 (or C3 ...): another BASELINE scene; --coarse: every 0.2 rad; --yaws=1.2,1.4: these offsets only
 """
 import importlib
 import math
@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 stamps = len(sys.argv) > 1 and sys.argv[1] == "stamps"
 if stamps:
-    os.environ["RTX_LIB"] = "librtx_hip_ablate.so"
+    os.environ["RTX_LIB"] = os.environ.get("RTX_STAMPS_LIB", "librtx_hip_ablate.so")
     os.environ["RTX_ABLATE"] = str(0x8000)
 import torch  # noqa: E402
 
@@ -30,6 +30,9 @@ W, H = int(p0.x), int(p0.y)
 yaws = [math.pi + 0.1 * k for k in range(25)]
 if any(a == "--coarse" for a in sys.argv[1:]):
     yaws = [math.pi + 0.2 * k for k in range(13)]
+for a in sys.argv[1:]:
+    if a.startswith("--yaws="):
+        yaws = [math.pi + float(v) for v in a.split("=")[1].split(",")]
 extra = [a for a in sys.argv[1:] if a.startswith("--")]
 for yaw in yaws:
     cam = R.camera_params(W, H, (0.0, 0.0, 0.0), (0.0, yaw, 0.0))

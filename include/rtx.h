@@ -137,6 +137,11 @@ enum rtx_option {
                                * caller's thread queues the root's (a rank's share is ~15 us of host work; on one thread 8 ranks cost 132 us per
                                * 1080p frame).  The call still returns only when everything is queued.  -1 auto (on where the list names two or
                                * more distinct devices; with all ranks on one GPU the threads were measured to change nothing), 0 off, 1 on */
+    RTX_OPT_UPDATE_HOST_WRITE = 19, /* the blocking rtx_update of a small frame (word form, one device, the caller's buffer from rtx_host_alloc or otherwise
+                               * pinned and device-addressable): the Minimize launch stores the stream and its length straight into host memory, so an
+                               * Update is three launches and ONE host wait instead of three launches, two copies and two waits -- at console sizes
+                               * (400 x 150) nothing else is left to save.  The same bytes.  -1 auto (frames up to 2^17 slots), 0 off, 1 on (any size:
+                               * the kernel then runs at PCIe speed) */
     RTX_OPT_GROUP_UPDATE = 18, /* device groups: how rtx_update / rtx_update_begin hand the minimised stream to the host.  0: the ranks' pixel words
                                * are gathered on the root, which minimises the frame and copies the stream over ITS PCIe link (the whole Update is
                                * bound by that copy: 0.33 ms per 1080p RGB frame).  1: no gather -- every rank traces its rows and the row above them,
@@ -162,6 +167,7 @@ enum rtx_stat {
     RTX_STAT_DENSITY_SWITCHES = 109,/* how often that changed */
     RTX_STAT_BATCHED_LAUNCHES = 114, /* launches that rendered several frames' slabs at once (RTX_OPT_BATCH) */
     RTX_STAT_GROUP_DIRECT_UPDATES = 116, /* Updates of a device group whose ranks minimised and copied their own rows (RTX_OPT_GROUP_UPDATE) */
+    RTX_STAT_UPDATE_HOST_WRITES = 117, /* blocking Updates whose Minimize launch wrote the caller's host buffer itself (RTX_OPT_UPDATE_HOST_WRITE) */
     RTX_STAT_MINIMIZE_FALLBACKS = 115, /* fused Minimize launches redone as three launches (RTX_OPT_MINIMIZE_FUSED) */
     RTX_STAT_GROUP_SIZE = 110,      /* logical ranks of the device group this context is the root of (1: a plain context) */
     RTX_STAT_GROUP_EXCHANGE = 111,  /* the exchange the last sharded frame used: RTX_EXCHANGE_PEER_COPY or RTX_EXCHANGE_RCCL (0: none yet) */

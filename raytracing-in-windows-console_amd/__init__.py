@@ -30,6 +30,8 @@ OPT_GROUP_EXCHANGE, OPT_GROUP_WIRE, OPT_BATCH, OPT_UPDATE_WORDS, OPT_GROUP_THREA
 STAT_BATCHED_LAUNCHES = 114
 OPT_MINIMIZE_FUSED = 17
 OPT_GROUP_UPDATE = 18
+OPT_UPDATE_HOST_WRITE = 19
+STAT_UPDATE_HOST_WRITES = 117
 STAT_GROUP_DIRECT_UPDATES = 116
 STAT_MINIMIZE_FALLBACKS = 115
 STAT_GROUP_SIZE, STAT_GROUP_EXCHANGE, STAT_GROUP_GATHERS, STAT_GROUP_BYTES = 110, 111, 112, 113

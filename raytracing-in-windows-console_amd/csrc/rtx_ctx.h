@@ -50,6 +50,8 @@ struct rtx_ctx {
     uint32_t* d_words = nullptr;    // rtx_update's pixel words (W * H; allocated on first use)
     size_t words_cap = 0;
     int64_t opt_update_words = -1;  // -1 auto (on), 0 off: rtx_update traces pixel words and minimises from them
+    int64_t opt_update_host_write = -1; // RTX_OPT_UPDATE_HOST_WRITE: -1 auto (frames up to 2^17 slots), 0 off, 1 on
+    uint64_t stat_host_writes = 0;
     uint64_t* h_pair = nullptr;     // two pinned words: a rank's stream length and failure word (rtx_update on a group, RTX_OPT_GROUP_UPDATE)
     uint64_t* d_look = nullptr;     // rtx_minw_fused's look-back tables (agg, grp: rtx_post.hip), zeroed when allocated
     size_t look_blocks = 0;         // ... sized for this many blocks
@@ -208,6 +210,14 @@ struct rtx_ctx {
         hipEvent_t ev_ready = nullptr, ev_copied = nullptr;
         size_t bytes = 0;
         bool busy = false;
+        // a small frame whose Minimize launch writes the caller's buffer itself (RTX_OPT_UPDATE_HOST_WRITE): nothing was waited for in
+        // rtx_update_begin; rtx_update_end waits for ev_ready and reads the length from h_total
+        bool host_write = false;
+        uint32_t hw_epoch = 0;
+        int hw_mode = 0;
+        size_t hw_w = 0, hw_h = 0;
+        const uint32_t* hw_words = nullptr;
+        uint8_t* hw_out = nullptr;
     };
     UpdateSlot upd[2];
     hipStream_t copy_stream = nullptr;

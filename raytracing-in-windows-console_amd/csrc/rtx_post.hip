@@ -175,7 +175,10 @@ int settle_minimize(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, co
 // Minimize from W*H pixel words on the context's stream: one launch (rtx_minw_fused, RTX_OPT_MINIMIZE_FUSED) or the three above.
 // (*d_total)[0] will hold the stream's length; after a fused launch (ctx->min_fused_epoch != 0) (*d_total)[1] == that epoch says
 // that blocks gave up: settle_minimize_words then redoes the frame with the three launches.
-int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total, uint32_t lead = 0)
+// (`pair`: where the one-launch form leaves the two result words instead of at d_scan -- pinned host memory as the device addresses it,
+// for a caller that reads them after a synchronisation without a copy; the three-launch form does not take it)
+int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t h, const uint32_t* d_words, uint8_t* d_out, uint64_t** d_total, uint32_t lead = 0,
+                          uint64_t* pair = nullptr)
 {
     const uint64_t n_slots = (uint64_t)w * h;
     const uint64_t n_blocks = (n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock;
@@ -189,7 +192,7 @@ int launch_minimize_words(rtx_ctx* ctx, void* d_scan, int mode, size_t w, size_t
         ctx->look_epoch = 1u;
     }
     const uint32_t epoch = ctx->look_epoch;
-    uint64_t* total = (uint64_t*)d_scan;
+    uint64_t* total = pair ? pair : (uint64_t*)d_scan;
     uint64_t* agg = ctx->d_look;
     uint64_t* grp = agg + ctx->look_blocks;
     const uint32_t ng = (uint32_t)(ctx->look_blocks / rtx::kLookGroup);
@@ -257,6 +260,49 @@ int trace_words(rtx_ctx* ctx, const rtx_params* p, int mode, uint32_t** own, siz
     if (rc != RTX_OK) return rc;
     if ((rc = rtx_render_rows(ctx, p, mode, 0, (size_t)p->y, *own, 0, ctx->stream, RTX_RENDER_COMPACT)) != RTX_OK) return rc;
     *d_words = *own;
+    return RTX_OK;
+}
+
+// The blocking Update of a small frame with ONE host wait: the Minimize launch stores the stream straight into the caller's buffer (pinned
+// host memory, addressed by the device) and its length into a pinned word, so that no copy is queued and nothing is waited for twice.
+// A console-sized frame's Update is three launches, two small copies and two waits -- 45 us of which the kernels are 11 -- and this
+// takes a copy, the stream's copy and a wait out of it.  *done = false: not this way (the buffer is not device-addressable, or the
+// one-launch Minimize is off): the caller goes the usual way.
+int update_host_write(rtx_ctx* ctx, const rtx_params* p, int mode, void* host_out, size_t* out_bytes, bool* done)
+{
+    *done = false;
+    if (ctx->opt_min_fused == 0 || ((uintptr_t)host_out & 15u) != 0) return RTX_OK;
+    RTX_HIP(ctx, hipSetDevice(ctx->device));
+    void* d_host = nullptr;
+    if (hipHostGetDevicePointer(&d_host, host_out, 0) != hipSuccess || d_host == nullptr) {
+        (void)hipGetLastError(); // pageable memory: the usual way
+        return RTX_OK;
+    }
+    if (!ctx->h_pair) {
+        if (hipHostMalloc((void**)&ctx->h_pair, 2 * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) {
+            ctx->h_pair = nullptr;
+            return rtx_fail(ctx, RTX_ERR_OUT_OF_MEMORY, "hipHostMalloc failed for the stream's length");
+        }
+    }
+    void* d_pair = nullptr;
+    RTX_HIP(ctx, hipHostGetDevicePointer(&d_pair, ctx->h_pair, 0));
+    const size_t W = (size_t)p->x, H = (size_t)p->y;
+    const uint32_t* d_words = nullptr;
+    int rc = trace_words(ctx, p, mode, &ctx->d_words, &ctx->words_cap, &d_words);
+    if (rc != RTX_OK) return rc;
+    const uint64_t n_slots = (uint64_t)W * H;
+    if ((rc = ensure_min_buffers(ctx, (size_t)((n_slots + rtx::kWSlotsPerBlock - 1) / rtx::kWSlotsPerBlock), false)) != RTX_OK) return rc;
+    ctx->h_pair[0] = 0;
+    ctx->h_pair[1] = 0;
+    uint64_t* d_total = nullptr;
+    if ((rc = launch_minimize_words(ctx, ctx->d_scan, mode, W, H, d_words, (uint8_t*)d_host, &d_total, 0u, (uint64_t*)d_pair)) != RTX_OK) return rc;
+    RTX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0;
+    // (blocks that gave up: the three launches, into the same buffer, their length read back the usual way)
+    if ((rc = settle_minimize_words(ctx, ctx->d_scan, mode, W, H, d_words, (uint8_t*)d_host, ctx->h_pair, &total)) != RTX_OK) return rc;
+    ctx->stat_host_writes++;
+    *out_bytes = (size_t)total;
+    *done = true;
     return RTX_OK;
 }
 
@@ -500,6 +546,16 @@ int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int 
             }
             (void)hipGetLastError(); // (the group gathers on its root from now on; this frame too)
         }
+        if (!ctx->group && (ctx->opt_update_host_write > 0 ||
+                            (ctx->opt_update_host_write < 0 && (uint64_t)params->x * (uint64_t)params->y <= (1u << 17)))) {
+            // a small frame: the Minimize launch writes the stream into the caller's pinned buffer itself (RTX_OPT_UPDATE_HOST_WRITE)
+            bool done = false;
+            if ((rc = update_host_write(ctx, params, mode, host_out, &n, &done)) != RTX_OK) return rc;
+            if (done) {
+                *out_bytes = n;
+                return RTX_OK;
+            }
+        }
         const uint32_t* d_words = nullptr;
         if ((rc = trace_words(ctx, params, mode, &ctx->d_words, &ctx->words_cap, &d_words)) != RTX_OK) return rc;
         if ((rc = rtx_minimize_words(ctx, mode, (size_t)params->x, (size_t)params->y, d_words, nullptr, &n)) != RTX_OK) return rc;
@@ -600,6 +656,33 @@ int rtx_update_begin(rtx_ctx* ctx, const rtx_params* params, int mode, double dt
     }
     uint64_t* d_total = nullptr;
     const uint32_t* d_words = nullptr;
+    sl.host_write = false;
+    if (from_words && !ctx->group && ctx->opt_min_fused != 0 && ((uintptr_t)host_out & 15u) == 0 &&
+        (ctx->opt_update_host_write > 0 || (ctx->opt_update_host_write < 0 && (uint64_t)w * h <= (1u << 17)))) {
+        // a small frame: the Minimize launch stores the stream and its length in host memory itself, and NOTHING is waited for here --
+        // rtx_update_end waits for the frame.  (At console sizes the copy form's two waits per frame were what the pipelined Update cost.)
+        void *d_host = nullptr, *d_pair = nullptr;
+        if (hipHostGetDevicePointer(&d_host, host_out, 0) == hipSuccess && d_host != nullptr && hipHostGetDevicePointer(&d_pair, sl.h_total, 0) == hipSuccess) {
+            if ((rc = trace_words(ctx, params, mode, &sl.d_words, &sl.words_cap, &d_words)) != RTX_OK) return rc;
+            sl.h_total[0] = 0;
+            sl.h_total[1] = 0;
+            if ((rc = launch_minimize_words(ctx, sl.d_scan, mode, w, h, d_words, (uint8_t*)d_host, &d_total, 0u, (uint64_t*)d_pair)) != RTX_OK) return rc;
+            RTX_HIP(ctx, hipEventRecord(sl.ev_ready, ctx->stream));
+            sl.host_write = true;
+            sl.hw_epoch = ctx->min_fused_epoch;
+            sl.hw_mode = mode;
+            sl.hw_w = w;
+            sl.hw_h = h;
+            sl.hw_words = d_words;
+            sl.hw_out = (uint8_t*)d_host;
+            ctx->stat_host_writes++;
+            sl.busy = true;
+            *ticket = (int)si;
+            ctx->upd_next = si ^ 1u;
+            return RTX_OK;
+        }
+        (void)hipGetLastError(); // pageable memory: the copy form
+    }
     if (from_words) {
         // pixel words into the slot's own buffer (a group: into the group's, gathered), minimised from there
         if ((rc = trace_words(ctx, params, mode, &sl.d_words, &sl.words_cap, &d_words)) != RTX_OK) return rc;
@@ -650,6 +733,17 @@ int rtx_update_end(rtx_ctx* ctx, int ticket, size_t* out_bytes)
     rtx_ctx::UpdateSlot& sl = ctx->upd[ticket];
     if (!sl.busy) return rtx_fail(ctx, RTX_ERR_INVALID_ARGUMENT, "rtx_update_end: no frame in flight under this ticket");
     RTX_HIP(ctx, hipSetDevice(ctx->device));
+    if (sl.host_write) {
+        RTX_HIP(ctx, hipEventSynchronize(sl.ev_ready));
+        sl.host_write = false;
+        sl.busy = false;
+        uint64_t total = 0;
+        ctx->min_fused_epoch = sl.hw_epoch;
+        const int rc = settle_minimize_words(ctx, sl.d_scan, sl.hw_mode, sl.hw_w, sl.hw_h, sl.hw_words, sl.hw_out, sl.h_total, &total);
+        if (rc != RTX_OK) return rc;
+        *out_bytes = (size_t)total;
+        return RTX_OK;
+    }
     RTX_HIP(ctx, hipEventSynchronize(sl.ev_copied));
     *out_bytes = sl.bytes;
     sl.busy = false;

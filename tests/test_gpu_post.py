@@ -632,3 +632,69 @@ def test_fused_record_minimize_is_the_two_launch_minimize(R, ctx, res):
         if w * h <= 1024 * 65:
             want = O.minimize(mode, frame, w, h)
             assert out[1].size == want.size and np.array_equal(out[1], want), (res, R.MODE_NAMES[mode])
+
+
+# ---- the blocking Update whose Minimize launch writes the caller's pinned buffer itself (RTX_OPT_UPDATE_HOST_WRITE)
+
+def test_update_host_write_hands_over_the_same_stream(R):
+    """Small frames take it by default (one host wait per Update): the oracle's stream in every mode, with physics steps in between,
+    equal to the copy form (option 0); a pageable buffer quietly goes the usual way; forced on at 1080p it is still the golden stream;
+    a Minimize whose blocks give up is redone into the same host buffer."""
+    import ctypes as C
+    sc = O.Scene.reference_default()
+    W, H = 400, 150
+    p = R.camera_params(W, H)
+    with R.Context(W, H) as c:
+        c.set_reference_default_scene()
+        assert c.get_option(R.OPT_UPDATE_HOST_WRITE) == -1
+        for k, mode in enumerate([R.BIT_ASCII, R.RGB_ASCII, R.RGB_PIXEL, R.BIT_PIXEL, R.RGB_NORMALS, R.SDL]):
+            O.lib().orc_update_objects(sc.ptrs(), sc.count, 0.03)
+            want = O.minimize(mode, O.render(U.oracle_params(p), sc, mode), W, H)
+            before = c.get_option(R.STAT_UPDATE_HOST_WRITES)
+            got = c.update(p, mode, dt=0.03, run_physics=True).copy()
+            assert got.size == want.size and np.array_equal(got, want), R.MODE_NAMES[mode]
+            assert c.get_option(R.STAT_UPDATE_HOST_WRITES) - before == (0 if mode == R.SDL else 1)
+            c.set_option(R.OPT_UPDATE_HOST_WRITE, 0)
+            again = c.update(p, mode).copy()                      # no physics step: the same scene, the copy form
+            assert np.array_equal(again, want)
+            c.set_option(R.OPT_UPDATE_HOST_WRITE, -1)
+        # blocks that give up: the three launches write the same host buffer
+        c.set_option(R.OPT_MINIMIZE_FUSED, 2)
+        want = O.minimize(R.RGB_ASCII, O.render(U.oracle_params(p), sc, R.RGB_ASCII), W, H)
+        assert np.array_equal(c.update(p, R.RGB_ASCII), want) and c.get_option(R.STAT_MINIMIZE_FALLBACKS) == 1
+        c.set_option(R.OPT_MINIMIZE_FUSED, -1)
+        # the pipelined form the same way: nothing is waited for in rtx_update_begin; blocks that give up are redone in rtx_update_end
+        bufs = [c.host_alloc(20 * W * H) for _ in range(2)]
+        try:
+            for fused in (-1, 2):
+                c.set_option(R.OPT_MINIMIZE_FUSED, fused)
+                before = c.get_option(R.STAT_UPDATE_HOST_WRITES)
+                t0 = c.update_begin(p, R.RGB_ASCII, bufs[0][0])
+                t1 = c.update_begin(p, R.BIT_ASCII, bufs[1][0])
+                n0, n1 = c.update_end(t0), c.update_end(t1)
+                assert np.array_equal(bufs[0][1][:n0], want)
+                assert np.array_equal(bufs[1][1][:n1], O.minimize(R.BIT_ASCII, O.render(U.oracle_params(p), sc, R.BIT_ASCII), W, H))
+                assert c.get_option(R.STAT_UPDATE_HOST_WRITES) - before == 2
+            c.set_option(R.OPT_MINIMIZE_FUSED, -1)
+        finally:
+            for ptr, _ in bufs:
+                c.host_free(ptr)
+        # a pageable destination: not device-addressable, so the stream is copied as before
+        before = c.get_option(R.STAT_UPDATE_HOST_WRITES)
+        buf = np.zeros(20 * W * H, dtype=np.uint8)
+        n = C.c_size_t()
+        rc = R.lib().rtx_update(c._h, C.byref(p), R.RGB_ASCII, 0.0, 0, buf.ctypes.data_as(C.c_void_p), C.byref(n))
+        assert rc == 0 and n.value == want.size and np.array_equal(buf[:n.value], want)
+        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == before
+        with pytest.raises(R.RtxError):
+            c.set_option(R.OPT_UPDATE_HOST_WRITE, 2)
+    gold = U.load_golden()["C2_RGB_ASCII"]
+    p2, sph2, pl2 = R.config_inputs("C2")
+    with R.Context(int(p2.x), int(p2.y)) as c:
+        c.set_scene(sph2, pl2)
+        got = c.update(p2, R.RGB_ASCII)
+        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 0        # 1080p: the copy form by default
+        c.set_option(R.OPT_UPDATE_HOST_WRITE, 1)
+        got = c.update(p2, R.RGB_ASCII)
+        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 1
+        assert len(got) == gold["minimized_bytes"] and O.fnv1a64(got) == gold["minimized_fnv1a64"]

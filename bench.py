@@ -205,6 +205,8 @@ def parse_args(argv=None):
                          "(trace + GPU minimise + copy of the minimised stream to the host), N=1 only")
     ap.add_argument("--update-records", action="store_true",
                     help="--what update: the record form of Update (RTX_OPT_UPDATE_WORDS = 0: records written, then minimised) instead of the default word form")
+    ap.add_argument("--update-host-write", type=int, default=-1, choices=[-1, 0, 1],
+                    help="--what update / update-async: RTX_OPT_UPDATE_HOST_WRITE (the Minimize launch writes the pinned host buffer itself; auto = small frames only)")
     ap.add_argument("--minimize-chain", action="store_true",
                     help="--what update: Minimize from words as three launches (RTX_OPT_MINIMIZE_FUSED = 0) instead of the default single launch")
     ap.add_argument("--physics", action="store_true", help="--what update: run the UpdateObjects step (dt 0.016) in every Update, as the reference does")
@@ -419,6 +421,8 @@ def run_single(args, torch, R):
         ctx.set_option(R.OPT_UPDATE_WORDS, 0)
     if args.minimize_chain:
         ctx.set_option(R.OPT_MINIMIZE_FUSED, 0)
+    if args.update_host_write != -1:
+        ctx.set_option(R.OPT_UPDATE_HOST_WRITE, args.update_host_write)
     ctx.render_rows(params, mode, 0, 1)   # uploads the scene
     ctx.synchronize()
     if args.frames_in_flight <= 0:

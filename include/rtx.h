@@ -137,11 +137,12 @@ enum rtx_option {
                                * caller's thread queues the root's (a rank's share is ~15 us of host work; on one thread 8 ranks cost 132 us per
                                * 1080p frame).  The call still returns only when everything is queued.  -1 auto (on where the list names two or
                                * more distinct devices; with all ranks on one GPU the threads were measured to change nothing), 0 off, 1 on */
-    RTX_OPT_UPDATE_HOST_WRITE = 19, /* the blocking rtx_update of a small frame (word form, one device, the caller's buffer from rtx_host_alloc or otherwise
-                               * pinned and device-addressable): the Minimize launch stores the stream and its length straight into host memory, so an
-                               * Update is three launches and ONE host wait instead of three launches, two copies and two waits -- at console sizes
-                               * (400 x 150) nothing else is left to save.  The same bytes.  -1 auto (frames up to 2^17 slots), 0 off, 1 on (any size:
-                               * the kernel then runs at PCIe speed) */
+    RTX_OPT_UPDATE_HOST_WRITE = 19, /* rtx_update / rtx_update_begin (word form, one device) when the caller's buffer is pinned, device-addressable memory
+                               * (rtx_host_alloc's is): the Minimize launch stores the stream and its length straight into host memory instead of
+                               * leaving them to two copies.  The blocking form then waits for the device ONCE (console-sized frames 45 -> 27 us per
+                               * Update, 1080p 0.395 -> 0.370 ms); the pipelined form does not wait at all before rtx_update_end (console sizes 35 ->
+                               * 19 us).  The same bytes; a pageable buffer quietly takes the copy form.  -1 auto (blocking: always; pipelined: frames
+                               * up to 2^17 slots -- beyond that a launch that runs at PCIe speed delays the next frame's kernels), 0 off, 1 on */
     RTX_OPT_GROUP_UPDATE = 18, /* device groups: how rtx_update / rtx_update_begin hand the minimised stream to the host.  0: the ranks' pixel words
                                * are gathered on the root, which minimises the frame and copies the stream over ITS PCIe link (the whole Update is
                                * bound by that copy: 0.33 ms per 1080p RGB frame).  1: no gather -- every rank traces its rows and the row above them,

@@ -693,8 +693,20 @@ def test_update_host_write_hands_over_the_same_stream(R):
     with R.Context(int(p2.x), int(p2.y)) as c:
         c.set_scene(sph2, pl2)
         got = c.update(p2, R.RGB_ASCII)
-        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 0        # 1080p: the copy form by default
-        c.set_option(R.OPT_UPDATE_HOST_WRITE, 1)
-        got = c.update(p2, R.RGB_ASCII)
-        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 1
+        assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 1        # the blocking form: at any size
         assert len(got) == gold["minimized_bytes"] and O.fnv1a64(got) == gold["minimized_fnv1a64"]
+        buf = c.host_alloc(20 * int(p2.x) * int(p2.y))
+        try:
+            n = c.update_end(c.update_begin(p2, R.RGB_ASCII, buf[0]))
+            assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 1    # the pipelined form at 1080p: the copy form
+            assert n == gold["minimized_bytes"] and O.fnv1a64(buf[1][:n]) == gold["minimized_fnv1a64"]
+            c.set_option(R.OPT_UPDATE_HOST_WRITE, 1)
+            n = c.update_end(c.update_begin(p2, R.RGB_ASCII, buf[0]))
+            assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 2
+            assert n == gold["minimized_bytes"] and O.fnv1a64(buf[1][:n]) == gold["minimized_fnv1a64"]
+            c.set_option(R.OPT_UPDATE_HOST_WRITE, 0)
+            got = c.update(p2, R.RGB_ASCII)
+            assert c.get_option(R.STAT_UPDATE_HOST_WRITES) == 2
+            assert len(got) == gold["minimized_bytes"] and O.fnv1a64(got) == gold["minimized_fnv1a64"]
+        finally:
+            c.host_free(buf[0])

@@ -4,7 +4,7 @@
 set -e
 TAG=${TAG:-r04_z}
 cd "$(dirname "$0")/.."
-for n in c1 c2 c2bit c3 c4 c5 update updaterec; do
+for n in c1 c2 c2bit c3 c4 c5 update updaterec updatecopy; do
   [ -f gpurun_out/${TAG}_${n}_kernel_stats.csv ] && cp gpurun_out/${TAG}_${n}_kernel_stats.csv profiles/
   [ -f gpurun_out/${TAG}_${n}_summary.json ] && cp gpurun_out/${TAG}_${n}_summary.json profiles/
 done

@@ -13,7 +13,7 @@ tail -3 gpurun_out/${TAG}_tests.log
 python bench.py > gpurun_out/${TAG}_bench_c2.json 2> gpurun_out/${TAG}_bench_c2.err; echo "bench rc $?"
 cat gpurun_out/${TAG}_bench_c2.json
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_c2_driver_form.json 2>/dev/null; echo "driver form rc $?"
-TAG=$TAG tools/r04_profile_gpu.sh c2 c2bit c1 c3 c4 c5 update updaterec
+TAG=$TAG tools/r04_profile_gpu.sh c2 c2bit c1 c3 c4 c5 update updaterec updatecopy
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_c2_inflight4/trace -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-moving-view --no-side-legs > gpurun_out/${TAG}_inflight4.log 2>&1; echo "inflight trace rc $?"
 python3 tools/overlap_from_trace.py gpurun_out/prof_${TAG}_c2_inflight4/trace > gpurun_out/${TAG}_c2_inflight4_overlap.json; echo "overlap rc $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_expand/trace -- python3 tools/expand_gpu.py > gpurun_out/${TAG}_expand.log 2>&1; echo "expand trace rc $?"

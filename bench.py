@@ -701,6 +701,41 @@ def run_single(args, torch, R):
                       "pcie_GBs_pipelined": round(nbytes / (async_ms * 1e-3) / 1e9, 2),
                       "minimized_bytes_match_golden": (nbytes == gm.get("minimized_bytes")) if gm.get("minimized_bytes") else None,
                       "bound": "PCIe (the device side of an Update is a few tens of microseconds; see DESIGN.md)"}
+        # ... and the reference's own workload: its default scene on a console-sized frame (400 x 150) in its start-up mode
+        # (BIT_ASCII, RayTracingManager.h:54), physics step included -- launches and host waits, nothing else, at this size
+        try:
+            cw, chh = 400, 150
+            with R.Context(cw, chh) as small:
+                small.set_reference_default_scene()
+                sp = R.camera_params(cw, chh)
+                for _ in range(200):
+                    got_small = small.update(sp, R.BIT_ASCII, dt=0.016, run_physics=True)
+                n_small = 2000
+                t_up = time.perf_counter()
+                for _ in range(n_small):
+                    got_small = small.update(sp, R.BIT_ASCII, dt=0.016, run_physics=True)
+                small_sync = (time.perf_counter() - t_up) * 1e6 / n_small
+                hb2 = [small.host_alloc(20 * cw * chh) for _ in range(2)]
+                tick = []
+                for i in range(n_small + 200):
+                    if i == 200:
+                        while tick:
+                            small.update_end(tick.pop(0))
+                        t_up = time.perf_counter()
+                    if len(tick) == 2:
+                        small.update_end(tick.pop(0))
+                    tick.append(small.update_begin(sp, R.BIT_ASCII, hb2[i % 2][0], dt=0.016, run_physics=True))
+                while tick:
+                    small.update_end(tick.pop(0))
+                small_async = (time.perf_counter() - t_up) * 1e6 / n_small
+                for p_, _ in hb2:
+                    small.host_free(p_)
+                end_to_end["console_frame"] = {"what": "the reference's default scene (Scene3D.cpp:28-33), 400 x 150, BIT_ASCII, UpdateObjects step included: "
+                                                       "whole Update per frame, wall clock over %d frames" % n_small,
+                                               "us_per_update_blocking": round(small_sync, 2), "us_per_update_pipelined": round(small_async, 2),
+                                               "bytes_per_update": int(len(got_small))}
+        except Exception as exc:   # (a side figure must not lose the line)
+            end_to_end["console_frame"] = {"error": repr(exc)}
     mrays = rays_per_frame * K / elapsed / 1e6
     g = golden().get("%s_%s" % (args.config, args.mode), {})
     hit_frac = (g.get("foreground_pixels") or 0) / float(rays_per_frame)

@@ -54,6 +54,28 @@ def config(name):
     return make
 
 
+if "--soak" in sys.argv:
+    # minutes of pipelined Updates of the default scene: every frame's length against the first's is not checked (the spheres move) --
+    # what is watched is that no Minimize launch ever gives up (RTX_STAT_MINIMIZE_FALLBACKS) and that the rate holds
+    secs = float(next((a.split("=")[1] for a in sys.argv if a.startswith("--seconds=")), "60"))
+    with R.Context(400, 150) as c:
+        c.set_reference_default_scene()
+        p = R.camera_params(400, 150)
+        hb = [c.host_alloc(20 * 400 * 150) for _ in range(2)]
+        tick, n, t0 = [], 0, time.perf_counter()
+        while time.perf_counter() - t0 < secs:
+            for _ in range(1000):
+                if len(tick) == 2:
+                    c.update_end(tick.pop(0))
+                tick.append(c.update_begin(p, (R.BIT_ASCII, R.RGB_ASCII)[n & 1], hb[n % 2][0], dt=0.016, run_physics=True))
+                n += 1
+        while tick:
+            c.update_end(tick.pop(0))
+        dt = time.perf_counter() - t0
+        print("soak: %d pipelined Updates in %.1f s (%.2f us each), Minimize launches that gave up: %d, host-write Updates %d" % (
+            n, dt, dt / n * 1e6, c.get_option(R.STAT_MINIMIZE_FALLBACKS), c.get_option(R.STAT_UPDATE_HOST_WRITES)), flush=True)
+    sys.exit(0)
+
 for mode in (R.BIT_ASCII, R.RGB_ASCII):
     run("reference default scene", default_scene(400, 150), 400, 150, mode)
     run("reference default scene", default_scene(200, 60), 200, 60, mode)

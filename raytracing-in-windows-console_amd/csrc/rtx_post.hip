@@ -546,7 +546,7 @@ int rtx_update(rtx_ctx* ctx, const rtx_params* params, int mode, double dt, int 
             }
             (void)hipGetLastError(); // (the group gathers on its root from now on; this frame too)
         }
-        if (!ctx->group && ctx->opt_update_host_write != 0) {
+        if (ctx->opt_update_host_write != 0) { // (a group that gathers on its root: the root's Minimize launch writes the host buffer)
             // the Minimize launch writes the stream into the caller's pinned buffer itself (RTX_OPT_UPDATE_HOST_WRITE): one host wait.  At
             // any size in this blocking form -- 1080p: 0.370 ms against 0.395 with the copy queued after a wait for the length
             bool done = false;
